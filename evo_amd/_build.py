@@ -1,0 +1,70 @@
+"""Builds libevo_mi355x.so (the C-ABI of include/evo_mi355x.h) from evo_amd/csrc/*.hip with hipcc for gfx950.
+
+In-tree build: the .so lands in evo_amd/_lib/ so it travels with the repo snapshot to the GPU box
+(it is git-ignored).  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "_lib"
+LIBNAME = "libevo_mi355x.so"
+ARCH = "gfx950"
+
+# every symbol include/evo_mi355x.h declares
+EXPORTS = [
+    "evo_abi_version", "evo_embed_bf16", "evo_rmsnorm_bf16", "evo_hyena_seg_state", "evo_hyena_carry_scan",
+    "evo_hyena_apply", "evo_hyena_step", "evo_rope_qk_bf16", "evo_attn_fwd_causal_bf16", "evo_gelu_gate_bf16",
+    "evo_logprob_entropy",
+]
+
+
+def lib_path() -> Path:
+    return LIBDIR / LIBNAME
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libevo_mi355x.so")
+
+
+def is_stale() -> bool:
+    out = lib_path()
+    if not out.exists():
+        return True
+    deps = list(sources()) + list(CSRC.glob("*.h")) + [ROOT.parent / "include" / "evo_mi355x.h"]
+    newest = max(p.stat().st_mtime for p in deps if p.exists())
+    return newest > out.stat().st_mtime
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source into one shared library.  Returns the library path."""
+    out = lib_path()
+    if not force and not is_stale():
+        return out
+    LIBDIR.mkdir(exist_ok=True)
+    tmp = out.with_suffix(".so.tmp%d" % os.getpid())
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fno-gpu-rdc", "-o", str(tmp)] + [str(s) for s in sources()]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    os.replace(tmp, out)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,270 @@
+// Causal multi-head attention forward for gfx950, head dim 128, bf16 in / fp32 softmax+accumulate /
+// bf16 out -- the kernel that stands where the reference calls FlashAttention-2.
+//
+// Workgroup = 4 waves = 128 consecutive queries of one (batch, head); wave w owns 32 query rows.  Keys
+// and values stream through LDS in tiles of 64 keys (next tile's global loads are issued before the
+// current tile's math and written to LDS after it).  Both GEMMs run "swapped" on
+// v_mfma_f32_32x32x16_bf16 so that the accumulator COLUMN is the query:
+//     S^T[key][q] = K . Q^T      (A = K tile from LDS,   B = Q fragment held in registers)
+//     O^T[d][q]   = V^T . P^T    (A = V^T tile from LDS, B = P^T built in-register from S^T)
+// With C/D layout col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5), every lane holds 16 of the 32
+// scores of ITS query per 32-key tile, so the online-softmax row reductions are 31 in-lane ops + one
+// exchange with lane^32, the rescale of O^T is lane-local, and P never goes through LDS.  The key
+// order inside an MFMA k-step is free as long as A and B agree, so P^T takes S^T's registers as they
+// are and the V^T fragment is fetched in the matching order (two 4-key groups per lane).
+//
+// LDS images (both conflict-free for their reads):
+//   Ks [64 keys][128 d] bf16, 16-byte slot XOR-swizzled by (key & 15)      -> ds_read_b128 A fragments
+//   Vt [128 d][64 keys] bf16, 8-byte  slot XOR-swizzled by ((d >> 1) & 15) -> ds_read_b64  A fragments
+// Entry point and reference citation: include/evo_mi355x.h.
+#include "common.h"
+#include "../../include/evo_mi355x.h"
+
+#define QB 128
+#define KB 64
+#define DH 128
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ mfma_bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(mfma_bf16x8, v); }
+
+struct AttnArgs {
+    const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o;
+    int64_t Tq, Tk, q_pos0;
+    int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh;
+    int H;
+    float scale_log2;      // softmax_scale * log2(e)
+    int n_qblocks;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KB * DH * 2];
+    unsigned char* Ks = smem;
+    unsigned char* Vt = smem + KB * DH * 2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int qb = a.n_qblocks - 1 - (int)blockIdx.x;      // longest (latest) query blocks first
+    const int head = blockIdx.y;
+    const int bat = blockIdx.z;
+    const int64_t q0 = (int64_t)qb * QB;
+
+    const uint16_t* qp = a.q + bat * a.q_sb + head * a.q_sh;
+    const uint16_t* kp = a.k + bat * a.k_sb + head * a.k_sh;
+    const uint16_t* vp = a.v + bat * a.v_sb + head * a.v_sh;
+
+    // ---- Q fragment: this lane's query row, 8 k-steps x 16 bytes -------------------------------------
+    const int64_t qrow = q0 + wave * 32 + l31;
+    const int64_t qrow_c = qrow < a.Tq ? qrow : a.Tq - 1;
+    uint4 qf[8];
+    {
+        const uint4* qr = (const uint4*)(qp + qrow_c * a.q_st);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = qr[2 * ks + half];
+    }
+
+    // ---- key range of this workgroup / wave -------------------------------------------------------------
+    int64_t q_last = q0 + QB - 1;
+    if (q_last > a.Tq - 1) q_last = a.Tq - 1;
+    int64_t max_key = q_last + a.q_pos0;
+    if (max_key > a.Tk - 1) max_key = a.Tk - 1;
+    const int n_tiles = (int)(max_key / KB) + 1;
+    const int64_t wq_first = q0 + wave * 32 + a.q_pos0;          // position limit of the wave's first row
+    const int64_t wq_last = wq_first + 31;
+    const int64_t my_lim = qrow + a.q_pos0;                       // this lane's query sees keys <= my_lim
+
+    // ---- staging maps ------------------------------------------------------------------------------------
+    const int kc = tid & 15;             // K: 16-byte chunk of the row
+    const int kr = tid >> 4;             // K: row (key) within each group of 16
+    const int vc = ((lane >> 4) << 2) | (lane & 3);        // V: 16-byte chunk (d = 8vc..8vc+7)
+    const int vm = 4 * wave + ((lane >> 2) & 3);           // V: key quad (keys 4vm..4vm+3)
+
+    // loads of one tile: wave-uniform tile base (SGPRs) + 32-bit per-lane byte offset; rows past the end
+    // of a ragged last tile are clamped to the last valid key (they are masked out of the softmax)
+    const uint32_t kst_b = (uint32_t)(a.k_st * 2), vst_b = (uint32_t)(a.v_st * 2);
+    uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;   // named (not arrays): must stay in VGPRs
+#define ATTN_LOAD_ONE(KR, VR, I, KB_PTR, VB_PTR, RELMAX)                                   \
+    {                                                                                      \
+        const int kk = min(kr + 16 * (I), (RELMAX));                                       \
+        const int vk = min(4 * vm + (I), (RELMAX));                                        \
+        KR = *(const uint4*)((KB_PTR) + (uint32_t)kk * kst_b + kc * 16);                   \
+        VR = *(const uint4*)((VB_PTR) + (uint32_t)vk * vst_b + vc * 16);                   \
+    }
+#define ATTN_ISSUE_LOADS(TILE)                                                             \
+    {                                                                                      \
+        const int64_t k0_ = (int64_t)(TILE) * KB;                                          \
+        const int64_t left_ = a.Tk - 1 - k0_;                                              \
+        const int rel_max_ = left_ < KB - 1 ? (int)left_ : KB - 1;                         \
+        const unsigned char* kb_ = (const unsigned char*)(kp + k0_ * a.k_st);              \
+        const unsigned char* vb_ = (const unsigned char*)(vp + k0_ * a.v_st);              \
+        ATTN_LOAD_ONE(kreg0, vreg0, 0, kb_, vb_, rel_max_)                                 \
+        ATTN_LOAD_ONE(kreg1, vreg1, 1, kb_, vb_, rel_max_)                                 \
+        ATTN_LOAD_ONE(kreg2, vreg2, 2, kb_, vb_, rel_max_)                                 \
+        ATTN_LOAD_ONE(kreg3, vreg3, 3, kb_, vb_, rel_max_)                                 \
+    }
+#define ATTN_KWRITE(KR, I)                                                                 \
+    {                                                                                      \
+        const int key_ = kr + 16 * (I);                                                    \
+        *(uint4*)(Ks + key_ * 256 + ((kc ^ (key_ & 15)) << 4)) = KR;                       \
+    }
+    // 4 keys x 2 d-values (one dword column J of the 4 loaded rows) -> two 8-byte V^T entries
+#define ATTN_VWRITE(J, C)                                                                  \
+    {                                                                                      \
+        const int d_even = 8 * vc + 2 * (J), d_odd = d_even + 1;                           \
+        uint2 ev, od;                                                                      \
+        ev.x = (vreg0.C & 0xffffu) | (vreg1.C << 16);                                      \
+        ev.y = (vreg2.C & 0xffffu) | (vreg3.C << 16);                                      \
+        od.x = (vreg0.C >> 16) | (vreg1.C & 0xffff0000u);                                  \
+        od.y = (vreg2.C >> 16) | (vreg3.C & 0xffff0000u);                                  \
+        *(uint2*)(Vt + d_even * 128 + ((vm ^ ((d_even >> 1) & 15)) << 3)) = ev;            \
+        *(uint2*)(Vt + d_odd * 128 + ((vm ^ ((d_odd >> 1) & 15)) << 3)) = od;              \
+    }
+#define ATTN_WRITE_LDS()                                                                   \
+    {                                                                                      \
+        ATTN_KWRITE(kreg0, 0) ATTN_KWRITE(kreg1, 1) ATTN_KWRITE(kreg2, 2) ATTN_KWRITE(kreg3, 3) \
+        ATTN_VWRITE(0, x) ATTN_VWRITE(1, y) ATTN_VWRITE(2, z) ATTN_VWRITE(3, w)            \
+    }
+
+    // V^T row offset of this lane per 32-row d-tile.  Laundered through an empty asm so hipcc keeps the
+    // two 8-byte fragment reads as ds_read_b64 (conflict-free here) instead of fusing rows 4 KiB apart
+    // into ds_read2st64_b64, which is serviced in 16-lane groups mod 32 banks (2-way conflict, half rate).
+    uint32_t vt_row[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        vt_row[dt] = (32 * dt + l31) * 128;
+        asm volatile("" : "+v"(vt_row[dt]));
+    }
+
+    f32x16_t oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY;     // running max (scaled, log2 domain)
+    float l_run = 0.f;           // this lane's share of the running denominator
+
+    ATTN_ISSUE_LOADS(0)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int64_t k0 = (int64_t)tile * KB;
+        ATTN_WRITE_LDS()
+        __syncthreads();
+        if (tile + 1 < n_tiles) ATTN_ISSUE_LOADS(tile + 1)
+
+        if (k0 <= wq_last) {                       // wave-uniform: at least one visible key
+            // ---- S^T = K . Q^T -----------------------------------------------------------------------------
+            f32x16_t sacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+                const int key = 32 * kt + l31;
+                const unsigned char* krow = Ks + key * 256;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const uint4 kf = *(const uint4*)(krow + (((2 * ks + half) ^ (key & 15)) << 4));
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf), as_frag(qf[ks]), sacc[kt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax (this lane = one query row, 32 of the tile's 64 keys) --------------------
+            const bool need_mask = (k0 + KB - 1 > wq_first) || (k0 + KB > a.Tk);
+            float tmax = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t kidx = k0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const bool ok = (kidx <= my_lim) && (kidx < a.Tk);
+                        sacc[kt][r] = ok ? sacc[kt][r] : -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kt][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax * a.scale_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run = -inf -> 0
+            float psum = 0.f;
+            uint32_t pk[2][8];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], a.scale_log2, -m_use));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r + 1], a.scale_log2, -m_use));
+                    psum += p0 + p1;
+                    pk[kt][r >> 1] = pack_bf2(p0, p1);
+                }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint4 pf;
+                    pf.x = pk[kt][4 * u]; pf.y = pk[kt][4 * u + 1]; pf.z = pk[kt][4 * u + 2]; pf.w = pk[kt][4 * u + 3];
+                    const int m1 = 8 * kt + 4 * u + half;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const int d = 32 * dt + l31;
+                        const int sw = (d >> 1) & 15;
+                        const unsigned char* vrow = Vt + vt_row[dt];
+                        const uint2 va = *(const uint2*)(vrow + ((m1 ^ sw) << 3));
+                        const uint2 vb = *(const uint2*)(vrow + (((m1 + 2) ^ sw) << 3));
+                        uint4 vf;
+                        vf.x = va.x; vf.y = va.y; vf.z = vb.x; vf.w = vb.y;
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf), as_frag(pf), oacc[dt], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise and store O[q][d] -----------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < a.Tq) {
+        uint16_t* orow = a.o + ((int64_t)(bat * a.Tq + qrow) * a.H + head) * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+                w.y = pack_bf2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+                *(uint2*)(orow + 32 * dt + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
+extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H,
+                                        int64_t Tq, int64_t Tk, int64_t q_pos0, int64_t q_sb, int64_t q_st,
+                                        int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh, int64_t v_sb,
+                                        int64_t v_st, int64_t v_sh, float softmax_scale, void* stream) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || q_pos0 < 0) return -1;
+    if ((q_st % 8) || (k_st % 8) || (v_st % 8) || (q_sh % 8) || (k_sh % 8) || (v_sh % 8) || (q_sb % 8) || (k_sb % 8) ||
+        (v_sb % 8))
+        return -1;   // 16-byte row accesses
+    if (H > 65535 || B > 65535) return -1;
+    AttnArgs a;
+    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (uint16_t*)o;
+    a.Tq = Tq; a.Tk = Tk; a.q_pos0 = q_pos0;
+    a.q_sb = q_sb; a.q_st = q_st; a.q_sh = q_sh; a.k_sb = k_sb; a.k_st = k_st; a.k_sh = k_sh;
+    a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
+    a.H = (int)H;
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    a.n_qblocks = (int)((Tq + QB - 1) / QB);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.n_qblocks, (unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    return evo_launch_status();
+}

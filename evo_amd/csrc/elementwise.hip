@@ -1,0 +1,303 @@
+// Memory-bound token-local kernels: embedding gather, RMSNorm(+bias/residual write), RoPE, GELU gate,
+// scoring tail.  All are HBM-bound: 16-byte (8 x bf16) accesses per lane, fp32 math, one rounding
+// on the way out.  Entry points and reference citations: include/evo_mi355x.h.
+#include "common.h"
+#include "../../include/evo_mi355x.h"
+
+// ------------------------------------------------------------------------------------------- embed
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const uint4* __restrict__ w,
+                                                    uint4* __restrict__ out, int64_t n_tok, int nvec) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = n_tok * nvec;
+    for (; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t tok = i / nvec;
+        int c = (int)(i - tok * nvec);
+        out[i] = w[ids[tok] * nvec + c];
+    }
+}
+
+extern "C" int evo_embed_bf16(const int64_t* ids, const void* weight, void* out, int64_t n_tok, int64_t D,
+                              int64_t vocab, void* stream) {
+    if (D % 8 != 0 || n_tok < 0 || vocab <= 0) return -1;
+    if (n_tok == 0) return 0;
+    int nvec = (int)(D / 8);
+    int64_t total = n_tok * nvec;
+    int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(embed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const uint4*)weight,
+                       (uint4*)out, n_tok, nvec);
+    return evo_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------- rmsnorm
+// One wave per row; the row (<= 4096 elements) stays in registers between the square-sum and the
+// scale pass, so HBM sees exactly one read and one write (two writes with the bias/residual form).
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+
+template <bool HAS_BIAS, int NV>   // NV = register-cached 16-byte vectors per lane (row <= NV*512 elements)
+__global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
+                                                      const uint4* __restrict__ scale, uint4* __restrict__ out,
+                                                      int64_t M, int nvec, float eps, float inv_sqrt_d) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        uint4* xr = x + row * nvec;
+        uint4 v[NV];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int idx = lane + 64 * i;
+            if (idx < nvec) {
+                v[i] = xr[idx];
+                float f[8];
+                unpack8(v[i], f);
+                if (HAS_BIAS) {
+                    float b[8];
+                    unpack8(bias[idx], b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += b[e];
+                    v[i] = pack8(f);            // the updated row is what is stored AND what is normed
+                    xr[idx] = v[i];
+                    unpack8(v[i], f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+            }
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+        uint4* orow = out + row * nvec;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int idx = lane + 64 * i;
+            if (idx < nvec) {
+                float f[8], s[8];
+                unpack8(v[i], f);
+                unpack8(scale[idx], s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = s[e] * (f[e] * inv);
+                orow[idx] = pack8(f);
+            }
+        }
+    }
+}
+
+// rows longer than the register cache: re-read the row for the second pass (served by L2)
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
+                                                           const uint4* __restrict__ scale, uint4* __restrict__ out,
+                                                           int64_t M, int nvec, float eps, float inv_sqrt_d) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        uint4* xr = x + row * nvec;
+        float ss = 0.f;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            uint4 v = xr[idx];
+            float f[8];
+            unpack8(v, f);
+            if (HAS_BIAS) {
+                float b[8];
+                unpack8(bias[idx], b);
+                for (int e = 0; e < 8; ++e) f[e] += b[e];
+                v = pack8(f);
+                xr[idx] = v;
+                unpack8(v, f);
+            }
+            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+        uint4* orow = out + row * nvec;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float f[8], s[8];
+            unpack8(xr[idx], f);
+            unpack8(scale[idx], s);
+            for (int e = 0; e < 8; ++e) f[e] = s[e] * (f[e] * inv);
+            orow[idx] = pack8(f);
+        }
+    }
+}
+
+extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D,
+                                float eps, void* stream) {
+    if (D % 8 != 0 || D <= 0 || M < 0) return -1;
+    if (M == 0) return 0;
+    int nvec = (int)(D / 8);
+    int64_t blocks = (M + 3) / 4;
+    int grid = (int)(blocks < 16384 ? blocks : 16384);
+    float isd = 1.0f / sqrtf((float)D);
+    hipStream_t s = (hipStream_t)stream;
+#define EVO_RMS_LAUNCH(K)                                                                                          \
+    hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, s, (uint4*)x, (const uint4*)bias, (const uint4*)scale,        \
+                       (uint4*)out, M, nvec, eps, isd)
+    if (nvec <= 64 * 2) {
+        if (bias) EVO_RMS_LAUNCH((rmsnorm_kernel<true, 2>)); else EVO_RMS_LAUNCH((rmsnorm_kernel<false, 2>));
+    } else if (nvec <= 64 * 8) {
+        if (bias) EVO_RMS_LAUNCH((rmsnorm_kernel<true, 8>)); else EVO_RMS_LAUNCH((rmsnorm_kernel<false, 8>));
+    } else {
+        if (bias) EVO_RMS_LAUNCH((rmsnorm_long_kernel<true>)); else EVO_RMS_LAUNCH((rmsnorm_long_kernel<false>));
+    }
+#undef EVO_RMS_LAUNCH
+    return evo_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------- rope
+// qkv [B,T,3,H,hd]; one thread rotates 8 pairs (i..i+7, i+hd/2..) of one (b,t,q|k,h) row.
+__global__ __launch_bounds__(256) void rope_kernel(uint4* __restrict__ qkv, const float4* __restrict__ cos_t,
+                                                   const float4* __restrict__ sin_t, int64_t B, int64_t T, int H,
+                                                   int hd) {
+    const int half_vec = hd / 16;                 // 16-byte vectors per half row
+    const int64_t total = B * T * 2 * H * half_vec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int c = (int)(i % half_vec);
+        int64_t r = i / half_vec;
+        int h = (int)(r % H); r /= H;
+        int which = (int)(r % 2); r /= 2;
+        int64_t t = r % T;
+        int64_t b = r / T;
+        int64_t row_vec = (((b * T + t) * 3 + which) * H + h) * (int64_t)(hd / 8);
+        uint4 a = qkv[row_vec + c];
+        uint4 bb = qkv[row_vec + half_vec + c];
+        float x0[8], x1[8], co[8], si[8];
+        unpack8(a, x0);
+        unpack8(bb, x1);
+        const float4* cp = cos_t + (t * (hd / 2) + c * 8) / 4;
+        const float4* sp = sin_t + (t * (hd / 2) + c * 8) / 4;
+        float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        co[0] = c0.x; co[1] = c0.y; co[2] = c0.z; co[3] = c0.w; co[4] = c1.x; co[5] = c1.y; co[6] = c1.z; co[7] = c1.w;
+        si[0] = s0.x; si[1] = s0.y; si[2] = s0.z; si[3] = s0.w; si[4] = s1.x; si[5] = s1.y; si[6] = s1.z; si[7] = s1.w;
+        float o0[8], o1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o0[e] = x0[e] * co[e] - x1[e] * si[e];
+            o1[e] = x0[e] * si[e] + x1[e] * co[e];
+        }
+        qkv[row_vec + c] = pack8(o0);
+        qkv[row_vec + half_vec + c] = pack8(o1);
+    }
+}
+
+extern "C" int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t, int64_t B, int64_t T, int64_t H,
+                                int64_t hd, void* stream) {
+    if (hd % 16 != 0 || B < 0 || T < 0) return -1;
+    int64_t total = B * T * 2 * H * (hd / 16);
+    if (total == 0) return 0;
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)qkv, (const float4*)cos_t,
+                       (const float4*)sin_t, B, T, (int)H, (int)hd);
+    return evo_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------- gelu gate
+__global__ __launch_bounds__(256) void gelu_gate_kernel(const uint4* __restrict__ g, uint4* __restrict__ a, int64_t M,
+                                                        int ivec) {
+    const int64_t total = M * ivec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t row = i / ivec;
+        int c = (int)(i - row * ivec);
+        const uint4* gr = g + row * 2 * ivec;
+        float u[8], w[8], o[8];
+        unpack8(gr[c], u);
+        unpack8(gr[ivec + c], w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float ge = 0.5f * u[e] * (1.0f + erff(u[e] * 0.70710678118654752f));   // exact-erf GELU
+            o[e] = ge * w[e];
+        }
+        a[i] = pack8(o);
+    }
+}
+
+extern "C" int evo_gelu_gate_bf16(const void* g, void* a, int64_t M, int64_t I, void* stream) {
+    if (I % 8 != 0 || M < 0) return -1;
+    int64_t total = M * (I / 8);
+    if (total == 0) return 0;
+    int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(gelu_gate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (uint4*)a, M,
+                       (int)(I / 8));
+    return evo_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------- scoring tail
+// one wave per row: fp32 log-softmax, gather of the target's log-prob, entropy -sum p log p.
+// Logits are bf16 (model output) or f32 (the generation loop's score buffer).
+template <bool F32>
+__device__ __forceinline__ float logit_at(const void* row, int64_t j) {
+    return F32 ? ((const float*)row)[j] : bf_to_f(((const uint16_t*)row)[j]);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void logprob_entropy_kernel(const void* __restrict__ logits,
+                                                              const int64_t* __restrict__ target,
+                                                              float* __restrict__ logprob, float* __restrict__ entropy,
+                                                              int64_t M, int V) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nvec = V / 8;                       // 8 logits per lane per step
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const char* lr = (const char*)logits + row * (int64_t)V * (F32 ? 4 : 2);
+        float m = -INFINITY;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float f[8];
+            if (F32) {
+                const float4 a = ((const float4*)lr)[2 * idx], b = ((const float4*)lr)[2 * idx + 1];
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+            } else {
+                unpack8(((const uint4*)lr)[idx], f);
+            }
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, f[e]);
+        }
+        m = wave_max(m);
+        float s1 = 0.f, s2 = 0.f;
+        for (int idx = lane; idx < nvec; idx += 64) {
+            float f[8];
+            if (F32) {
+                const float4 a = ((const float4*)lr)[2 * idx], b = ((const float4*)lr)[2 * idx + 1];
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+            } else {
+                unpack8(((const uint4*)lr)[idx], f);
+            }
+            for (int e = 0; e < 8; ++e) {
+                float d = f[e] - m;
+                float ex = __expf(d);
+                s1 += ex;
+                s2 = fmaf(ex, d, s2);
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float logz = logf(s1);
+        if (lane == 0) {
+            if (entropy) entropy[row] = logz - s2 / s1;
+            if (logprob) {
+                int64_t tg = target ? target[row] : -1;
+                logprob[row] = (tg >= 0 && tg < V) ? logit_at<F32>(lr, tg) - m - logz : 0.f;
+            }
+        }
+    }
+}
+
+extern "C" int evo_logprob_entropy(const void* logits, int64_t logits_f32, const int64_t* target, float* logprob,
+                                   float* entropy, int64_t M, int64_t V, void* stream) {
+    if (V % 8 != 0 || M < 0) return -1;
+    if (M == 0) return 0;
+    int64_t blocks = (M + 3) / 4;
+    int grid = (int)(blocks < 16384 ? blocks : 16384);
+    if (logits_f32)
+        hipLaunchKernelGGL(logprob_entropy_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target,
+                           logprob, entropy, M, (int)V);
+    else
+        hipLaunchKernelGGL(logprob_entropy_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
+                           target, logprob, entropy, M, (int)V);
+    return evo_launch_status();
+}
+
+extern "C" int evo_abi_version(void) { return 1; }

@@ -1,0 +1,175 @@
+"""Sampling with the reference's `Generator.generate` / `generate` interface [REF evo/generation.py:13-297].
+
+The token loop stays host-side Python, as in the reference.  Two deliberate differences:
+
+1. Prompt handling.  The reference prefills only the first `force_prompt_threshold` (default 128)
+   prompt tokens in parallel and pushes the rest through the recurrence one token at a time
+   [REF evo/generation.py:81-88,131-189], because upstream's FFT prefill materialises [B,D,8,2T]
+   temporaries.  This engine's long-convolution kernel already ends with the exact modal state, so
+   by default (`force_prompt_threshold=None`) the WHOLE prompt is prefilled in one parallel pass.
+   Passing an integer threshold reproduces the reference's schedule.
+2. Cache offsets.  After its short prefill the reference jumps `seqlen_offset` to the full prompt
+   length [REF evo/generation.py:142-145], so teacher-forced tokens get rotary positions starting at P
+   and KV rows [threshold, P) are never written.  Here the offset always equals the
+   number of tokens actually cached; `legacy_offsets=True` restores the reference behaviour.
+
+The shifted score pairing of the wrapper [REF evo/generation.py:287; evo/scoring.py:48-50] is kept
+verbatim so reported scores match.
+"""
+import sys
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from .scoring import logits_to_logprobs, prepare_batch
+from .sh.sample import sample
+from .tokenizer import CharLevelTokenizer
+
+
+class Generator:
+    def __init__(self, model, tokenizer: CharLevelTokenizer, top_k: int = 50, top_p: float = 0.7,
+                 temperature: float = 1.0):
+        self.model = model
+        self.tokenizer = tokenizer
+        self.top_k = top_k
+        self.top_p = top_p
+        self.temperature = temperature
+        self.untils = ["\n\n"]
+
+    def _rehome_cache(self, cache: dict, device) -> None:
+        """Cached tensors follow the input's device [REF evo/generation.py:105-114]."""
+        for store in (cache["mha"].key_value_memory_dict, cache["hyena"].fir_state_dict,
+                      cache["hyena"].state_dict):
+            for key, t in store.items():
+                store[key] = t.to(device)
+
+    def generate(self, device: str, input_string: str = None, input_ids: torch.Tensor = None,
+                 num_tokens: int = 32, cached_generation: bool = True, force_prompt_threshold: int = None,
+                 print_generation: bool = True, verbose: bool = False, skip_special_tokens: bool = False,
+                 stop_at_eos: bool = True, max_seqlen: int = None, inference_params_dict: dict = None,
+                 legacy_offsets: bool = False) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+        """Returns (generated ids [B, n], the logits that produced them [B, n, V] f32, cache dict)."""
+        tok = self.tokenizer
+        eos_ids = torch.LongTensor([tok.eos]).to(device) if isinstance(tok.eos, int) \
+            else tok.tokenize(tok.eos).to(device)
+        if input_ids is None:
+            enc = tok.tokenize(input_string)
+            prompt = torch.LongTensor([int(t) for t in enc]).unsqueeze(0).to(device) if isinstance(enc, list) \
+                else enc.unsqueeze(0).to(device)
+        else:
+            prompt = input_ids
+        x = prompt if max_seqlen is None else prompt[:, -max_seqlen:]
+
+        num_tokens = int(num_tokens)
+        B, P = x.shape
+        x_force = None
+        n_forced = 0
+        if force_prompt_threshold is not None and P > force_prompt_threshold:
+            n_forced = P - force_prompt_threshold
+            x_force = x[:, force_prompt_threshold:]
+            x = x[:, :force_prompt_threshold]
+
+        generation = torch.empty(B, num_tokens, dtype=torch.long, device=x.device)
+        scores = torch.empty(B, num_tokens, tok.vocab_size, dtype=torch.float, device=x.device)
+
+        prefilled = False
+        if inference_params_dict is not None:
+            cached_generation = True
+            prefilled = True
+            self._rehome_cache(inference_params_dict, x.device)
+        elif cached_generation:
+            inference_params_dict = self.model.initialize_inference_params()
+            inference_params_dict["mha"].max_batch_size = B
+            inference_params_dict["hyena"].max_batch_size = B
+
+        if verbose:
+            print("Starting generation...")
+            print("Prompt: " + input_string if input_string is not None else f"Prompt ids: {input_ids} {input_ids.shape}")
+
+        total_steps = n_forced + num_tokens
+        i = -1
+        for i in range(total_steps):
+            post_prefill = prefilled or (cached_generation and i > 0)
+            if post_prefill:
+                x = x[:, -1:]
+                mha, hy = inference_params_dict["mha"], inference_params_dict["hyena"]
+                if mha.seqlen_offset == 0:
+                    first = prompt.shape[-1] if legacy_offsets else (P - n_forced)
+                    mha.seqlen_offset = hy.seqlen_offset = first
+                else:
+                    mha.seqlen_offset += 1
+                    hy.seqlen_offset += 1
+            with torch.inference_mode():
+                logits, inference_params_dict = self.model(x, inference_params_dict=inference_params_dict)
+            last_logits = logits[:, -1]
+
+            if i < n_forced:
+                new_idx = x_force[:, i]                               # teacher forcing of the prompt tail
+            else:
+                new_idx = sample(last_logits, top_k=self.top_k, top_p=self.top_p, temperature=self.temperature)
+                j = i - n_forced
+                scores[:, j] = last_logits
+                generation[:, j] = new_idx
+
+            if stop_at_eos and num_tokens >= 2 and bool((generation[0, -2:] == eos_ids).all()):
+                print("Stopping generation at EOS")
+            if print_generation and verbose and B == 1:
+                print(f"{tok.detokenize([new_idx.item()])}", end=" ")
+
+            x = new_idx[:, None] if post_prefill else torch.cat([x, new_idx[:, None]], dim=-1)
+
+        if verbose:
+            y = tok.detokenize_batch(generation[:, : i + 1])
+            for until in self.untils:
+                if until in y:
+                    y = y.split(until)[0]
+                    break
+            print(f"\nInput: {input_string}, Output: {y}")
+        return generation[:, : i + 1], scores[:, : i + 1], inference_params_dict
+
+
+def generate(prompt_seqs: List[str], model, tokenizer: CharLevelTokenizer, n_tokens: int = 100,
+             temperature: float = 0.0, top_k: int = 1, top_p: float = 1.0, batched: bool = True,
+             prepend_bos: bool = False, cached_generation: bool = False, force_prompt_threshold: int = None,
+             verbose: int = 1, device: str = "cuda:0", **kwargs) -> Tuple[List[str], List[float]]:
+    """Generate `n_tokens` after each prompt.  Equal-length prompts run as one batch when `batched`.
+    Returns (generated strings, mean log-likelihood score per generation)."""
+    if hasattr(model, "eval"):
+        model.eval()
+    g = Generator(model, tokenizer, top_k=top_k, top_p=top_p, temperature=temperature)
+
+    same_len = all(len(s) == len(prompt_seqs[0]) for s in prompt_seqs)
+    if batched and same_len:
+        batches = [prepare_batch(prompt_seqs, tokenizer, prepend_bos=prepend_bos, device=device)[0]]
+    else:
+        if verbose:
+            if not same_len:
+                sys.stderr.write("Note: Prompts are of different lengths.\n")
+            sys.stderr.write("Note: Will not do batched generation.\n")
+        batches = [prepare_batch([s], tokenizer, prepend_bos=prepend_bos, device=device)[0] for s in prompt_seqs]
+
+    seqs_out: List[str] = []
+    scores_out: List[float] = []
+    for input_ids in batches:
+        bsz = input_ids.shape[0]
+        output_ids, logits, _ = g.generate(
+            input_ids=input_ids, num_tokens=n_tokens, cached_generation=cached_generation,
+            force_prompt_threshold=force_prompt_threshold, device=device, print_generation=(verbose > 1),
+            verbose=(verbose > 1), stop_at_eos=False, legacy_offsets=bool(kwargs.get("legacy_offsets", False)))
+        if verbose > 1:
+            print("input_ids.shape", input_ids.shape)
+            print("output_ids.shape", output_ids.shape)
+            print("logits.shape", logits.shape)
+        decoded = list(tokenizer.detokenize_batch(output_ids))
+        assert len(decoded) == bsz
+        seqs_out += decoded
+        # same pairing as the reference: logits j vs token j+1 (default trim_bos=True)
+        lp = logits_to_logprobs(logits, output_ids).float().cpu().numpy()
+        scores_out += [np.mean(lp[b]) for b in range(bsz)]
+
+    assert len(seqs_out) == len(scores_out) == len(prompt_seqs)
+    if verbose:
+        for seq, score, prompt in zip(seqs_out, scores_out, prompt_seqs):
+            print(f'Prompt: "{prompt}",\tOutput: "{seq}",\tScore: {score}')
+    return seqs_out, scores_out

@@ -1,0 +1,275 @@
+"""ctypes binding of libevo_mi355x.so (include/evo_mi355x.h) and the op set the StripedHyena host code calls.
+
+`HipOps` is the ONLY compute backend the product ships: it raises if the shared library cannot be
+loaded or a tensor is not on a ROCm device -- there is no CPU / eager fallback.  Dense layers go to
+hipBLASLt through `torch.addmm` (SURVEY.md section 7 decision D1); everything else is a hand-written gfx950
+kernel reached through the C ABI with raw device pointers and the caller's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _build
+
+_c = ctypes
+_PTR = _c.c_void_p
+_I64 = _c.c_int64
+_F32 = _c.c_float
+
+_SIGNATURES = {
+    "evo_abi_version": ([], _c.c_int),
+    "evo_embed_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_rmsnorm_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _PTR], _c.c_int),
+    "evo_hyena_seg_state": ([_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_hyena_carry_scan": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_hyena_apply": ([_PTR] * 9 + [_I64] * 5 + [_PTR], _c.c_int),
+    "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR], _c.c_int),
+    "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
+    "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
+}
+
+_LIB = None
+
+
+class EvoLibraryError(RuntimeError):
+    pass
+
+
+def load_library(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load libevo_mi355x.so and type every entry point.  Raises EvoLibraryError when it is absent and
+    cannot be built -- the product path never degrades to a non-HIP implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.lib_path()
+    if (not path.exists() or (_build.is_stale() and os.environ.get("EVO_AMD_NO_REBUILD") != "1")) and build_if_missing:
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not path.exists():
+                raise EvoLibraryError(f"libevo_mi355x.so is missing and could not be built: {e}") from e
+    if not path.exists():
+        raise EvoLibraryError(f"{path} not found; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(str(path))
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise EvoLibraryError(f"{path} does not export {name}")
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _LIB = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check(code: int, name: str):
+    if code != 0:
+        raise RuntimeError(f"{name} failed with hipError/arg code {code}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pick_segment_length(B: int, T: int, H: int, target_waves: int = 8192) -> int:
+    """Time-segment length C of the Hyena kernels: enough (b, head, segment) waves to fill 256 CUs,
+    power of two in [64, 1024]."""
+    c = 1024
+    while c > 64 and B * H * ((T + c - 1) // c) < target_waves:
+        c //= 2
+    return c
+
+
+class HipOps:
+    """The gfx950 op set.  All tensors must live on the same ROCm device."""
+
+    name = "hip-gfx950"
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EvoLibraryError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.seg_len_override = int(os.environ.get("EVO_AMD_SEG_LEN", "0"))
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    @staticmethod
+    def _need(t: torch.Tensor, dtype, what: str):
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path has no CPU fallback")
+        if t.dtype != dtype:
+            raise RuntimeError(f"{what}: expected {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{what}: tensor must be contiguous")
+
+    # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16."""
+        if b is not None:
+            return torch.addmm(b, x, w.t())
+        return torch.mm(x, w.t())
+
+    def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """res += x @ w^T (fp32 accumulate, one rounding), in place."""
+        return res.addmm_(x, w.t())
+
+    # ---- kernels -------------------------------------------------------------------------------------
+    def embed(self, ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        ids = ids.reshape(-1).to(torch.int64).contiguous()
+        self._need(ids, torch.int64, "embed ids")
+        self._need(weight, torch.bfloat16, "embed weight")
+        V, D = weight.shape
+        out = torch.empty(ids.numel(), D, dtype=torch.bfloat16, device=weight.device)
+        _check(self.lib.evo_embed_bf16(ids.data_ptr(), weight.data_ptr(), out.data_ptr(), ids.numel(), D, V,
+                                       _stream()), "evo_embed_bf16")
+        return out
+
+    def rmsnorm(self, x: torch.Tensor, bias: Optional[torch.Tensor], scale: torch.Tensor, eps: float) -> torch.Tensor:
+        """out = scale * x / (rms(x) + eps); with `bias`, x is first updated in place (x += bias)."""
+        self._need(x, torch.bfloat16, "rmsnorm x")
+        self._need(scale, torch.bfloat16, "rmsnorm scale")
+        if bias is not None:
+            self._need(bias, torch.bfloat16, "rmsnorm bias")
+        M, D = x.shape
+        out = torch.empty_like(x)
+        _check(self.lib.evo_rmsnorm_bf16(x.data_ptr(), _ptr(bias), scale.data_ptr(), out.data_ptr(), M, D,
+                                         float(eps), _stream()), "evo_rmsnorm_bf16")
+        return out
+
+    def hyena_prefill(self, z: torch.Tensor, fir_w: torch.Tensor, fir_b: torch.Tensor, poles: torch.Tensor,
+                      residues: torch.Tensor, dskip: torch.Tensor, n_heads: int,
+                      z_halo: Optional[torch.Tensor] = None, s0: Optional[torch.Tensor] = None,
+                      want_state: bool = False, seg_len: Optional[int] = None
+                      ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """z [B,T,3D] bf16 -> y [B,T,D] bf16 (+ complex64 state [B,D,8] after the last token)."""
+        self._need(z, torch.bfloat16, "hyena z")
+        B, T, D3 = z.shape
+        D = D3 // 3
+        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b"), (dskip, "dskip")):
+            self._need(t, torch.bfloat16, "hyena " + nm)
+        self._need(poles, torch.float32, "hyena poles")
+        self._need(residues, torch.float32, "hyena residues")
+        if z_halo is not None:
+            self._need(z_halo, torch.bfloat16, "hyena z_halo")
+            assert z_halo.shape == (B, 2, D3)
+        s0r = None
+        if s0 is not None:
+            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
+            assert s0r.shape == (B, D, 8, 2)
+        C = seg_len or self.seg_len_override or pick_segment_length(B, T, n_heads)
+        n_seg = (T + C - 1) // C
+        agg = torch.empty(B, n_seg, D, 8, 2, dtype=torch.float32, device=z.device)
+        y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
+        s_final = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device) if want_state else None
+        st = _stream()
+        _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                            poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+               "evo_hyena_seg_state")
+        _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), _ptr(s0r), _ptr(s_final), B, T, D, C,
+                                             st), "evo_hyena_carry_scan")
+        _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                        poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
+                                        y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
+        state = torch.view_as_complex(s_final) if want_state else None
+        return y, state
+
+    def hyena_end_state(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
+        """State after the last token of z from a ZERO entering state (sequence-parallel pass 1)."""
+        B, T, D3 = z.shape
+        D = D3 // 3
+        C = seg_len or self.seg_len_override or pick_segment_length(B, T, n_heads)
+        n_seg = (T + C - 1) // C
+        agg = torch.empty(B, n_seg, D, 8, 2, dtype=torch.float32, device=z.device)
+        s_final = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
+        st = _stream()
+        _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                            poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+               "evo_hyena_seg_state")
+        _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), None, s_final.data_ptr(), B, T, D, C,
+                                             st), "evo_hyena_carry_scan")
+        return torch.view_as_complex(s_final)
+
+    def hyena_step(self, z_t: torch.Tensor, fir_state: torch.Tensor, iir_state: torch.Tensor, fir_w, fir_b, poles,
+                   residues, dskip, n_heads: int) -> torch.Tensor:
+        """One decode step; fir_state [B,3D,2] bf16 and iir_state [B,D,8] complex64 are updated in place."""
+        self._need(z_t, torch.bfloat16, "hyena_step z_t")
+        self._need(fir_state, torch.bfloat16, "hyena_step fir_state")
+        if iir_state.dtype != torch.complex64 or not iir_state.is_contiguous():
+            raise RuntimeError("hyena_step: iir_state must be contiguous complex64")
+        B, D3 = z_t.shape
+        D = D3 // 3
+        y = torch.empty(B, D, dtype=torch.bfloat16, device=z_t.device)
+        sr = torch.view_as_real(iir_state)
+        _check(self.lib.evo_hyena_step(z_t.data_ptr(), fir_state.data_ptr(), sr.data_ptr(), fir_w.data_ptr(),
+                                       fir_b.data_ptr(), poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(),
+                                       y.data_ptr(), B, D, n_heads, _stream()), "evo_hyena_step")
+        return y
+
+    def rope_(self, qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        """In-place NeoX rotary on the q and k thirds of qkv [B,T,3,H,hd]."""
+        self._need(qkv, torch.bfloat16, "rope qkv")
+        self._need(cos, torch.float32, "rope cos")
+        self._need(sin, torch.float32, "rope sin")
+        B, T, three, H, hd = qkv.shape
+        assert three == 3 and cos.shape == (T, hd // 2)
+        _check(self.lib.evo_rope_qk_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, T, H, hd, _stream()),
+               "evo_rope_qk_bf16")
+        return qkv
+
+    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos0: int) -> torch.Tensor:
+        """Causal attention; q [B,Tq,H,128], k/v [B,Tk,H,128] (strided views allowed, last dim dense)."""
+        for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+            if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
+                raise RuntimeError(f"attention {nm}: need a ROCm bf16 tensor with a dense last dim")
+        B, Tq, H, hd = q.shape
+        Tk = k.shape[1]
+        if hd != 128:
+            raise RuntimeError("attention: head dim must be 128")
+        o = torch.empty(B, Tq, H, hd, dtype=torch.bfloat16, device=q.device)
+        _check(self.lib.evo_attn_fwd_causal_bf16(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
+            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+            v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _stream()), "evo_attn_fwd_causal_bf16")
+        return o
+
+    def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:
+        self._need(g, torch.bfloat16, "gelu_gate g")
+        M, I2 = g.shape
+        a = torch.empty(M, I2 // 2, dtype=torch.bfloat16, device=g.device)
+        _check(self.lib.evo_gelu_gate_bf16(g.data_ptr(), a.data_ptr(), M, I2 // 2, _stream()), "evo_gelu_gate_bf16")
+        return a
+
+    def logprob_entropy(self, logits: torch.Tensor, target: Optional[torch.Tensor], want_logprob=True,
+                        want_entropy=False):
+        """logits [M,V] bf16|f32, target [M] int64 -> (logprob [M] f32 | None, entropy [M] f32 | None)."""
+        if logits.dtype not in (torch.bfloat16, torch.float32):
+            raise RuntimeError(f"logprob logits: expected bf16 or f32, got {logits.dtype}")
+        self._need(logits, logits.dtype, "logprob logits")
+        M, V = logits.shape
+        lp = torch.empty(M, dtype=torch.float32, device=logits.device) if want_logprob else None
+        en = torch.empty(M, dtype=torch.float32, device=logits.device) if want_entropy else None
+        if target is not None:
+            target = target.reshape(-1).to(torch.int64).contiguous()
+        _check(self.lib.evo_logprob_entropy(logits.data_ptr(), int(logits.dtype == torch.float32), _ptr(target),
+                                            _ptr(lp), _ptr(en), M, V, _stream()),
+               "evo_logprob_entropy")
+        return lp, en
+
+
+_DEFAULT_OPS = None
+
+
+def default_ops() -> HipOps:
+    global _DEFAULT_OPS
+    if _DEFAULT_OPS is None:
+        _DEFAULT_OPS = HipOps()
+    return _DEFAULT_OPS

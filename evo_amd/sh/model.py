@@ -1,0 +1,348 @@
+"""`stripedhyena.model.StripedHyena` mirror: the host side of the MI355X-native forward engine.
+
+The class keeps the contract evo consumes [REF evo/models.py:146-150; evo/scoring.py:81;
+evo/generation.py:105-155]:
+    model = StripedHyena(config); model.load_state_dict(sd, strict=True)
+    model.to_bfloat16_except_poles_residues(); model.to(device)
+    logits, cache = model(input_ids, inference_params_dict=None, padding_mask=None)
+    cache = model.initialize_inference_params()
+with the state-dict key set of SURVEY.md section B.  All arithmetic is dispatched to an `ops` object:
+`evo_amd.ops.HipOps` (hand-written gfx950 kernels over the C ABI + hipBLASLt GEMMs) in the product.
+There is no CPU fallback here: with no `ops` injected and no usable HIP library the first forward raises.
+(`tests/` inject an oracle-backed ops object to exercise this host logic on CPU.)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .cache import InferenceParams, RecurrentInferenceParams
+from .utils import dotdict
+
+
+def _cfg(config, key, default):
+    v = config.get(key, None) if isinstance(config, dict) else getattr(config, key, None)
+    return default if v is None else v
+
+
+class _Params(nn.Module):
+    """A bag of named parameters (keeps the upstream module/parameter names for state-dict parity)."""
+
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, (shape, dtype) in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.empty(*shape, dtype=dtype), requires_grad=False))
+
+
+class _MLP(nn.Module):
+    def __init__(self, D, inner):
+        super().__init__()
+        bf = torch.bfloat16
+        self.l1 = _Params(weight=((inner, D), bf))
+        self.l2 = _Params(weight=((inner, D), bf))
+        self.l3 = _Params(weight=((D, inner), bf))
+
+
+class _HyenaBlock(nn.Module):
+    """ParallelGatedConvBlock parameters."""
+
+    def __init__(self, D, inner, state_size, filt_len):
+        super().__init__()
+        bf = torch.bfloat16
+        self.pre_norm = _Params(scale=((D,), bf))
+        self.post_norm = _Params(scale=((D,), bf))
+        self.projections = _Params(weight=((3 * D, D), bf), bias=((3 * D,), bf))
+        self.filter = _Params(short_filter_weight=((3 * D, 1, filt_len), bf), short_filter_bias=((3 * D,), bf),
+                              D=((D,), bf), poles=((D, state_size, 1, 2), torch.float32),
+                              residues=((D, state_size, 1, 2), torch.float32))
+        self.out_filter_dense = _Params(weight=((D, D), bf), bias=((D,), bf))
+        self.mlp = _MLP(D, inner)
+
+
+class _MHA(nn.Module):
+    def __init__(self, D, hd):
+        super().__init__()
+        bf = torch.bfloat16
+        self.Wqkv = _Params(weight=((3 * D, D), bf), bias=((3 * D,), bf))
+        self.out_proj = _Params(weight=((D, D), bf), bias=((D,), bf))
+        self.rotary_emb = nn.Module()
+        self.rotary_emb.register_buffer("inv_freq", torch.empty(hd // 2, dtype=torch.float32), persistent=True)
+
+
+class _AttentionBlock(nn.Module):
+    def __init__(self, D, inner, hd):
+        super().__init__()
+        bf = torch.bfloat16
+        self.pre_norm = _Params(scale=((D,), bf))
+        self.post_norm = _Params(scale=((D,), bf))
+        self.inner_mha_cls = _MHA(D, hd)
+        self.mlp = _MLP(D, inner)
+
+
+class StripedHyena(nn.Module):
+    def __init__(self, config, ops=None):
+        super().__init__()
+        if not isinstance(config, dict):
+            raise TypeError("config must be a dict / dotdict")
+        self.config = config if isinstance(config, dotdict) else dotdict(config)
+        c = self.config
+        self.vocab_size = int(_cfg(c, "vocab_size", 512))
+        self.hidden_size = D = int(_cfg(c, "hidden_size", 4096))
+        self.num_layers = int(_cfg(c, "num_layers", 32))
+        self.attn_layer_idxs = list(_cfg(c, "attn_layer_idxs", [8, 16, 24]))
+        self.hyena_layer_idxs = list(_cfg(c, "hyena_layer_idxs",
+                                          [i for i in range(self.num_layers) if i not in self.attn_layer_idxs]))
+        self.num_heads = int(_cfg(c, "num_attention_heads", 32))
+        self.head_dim = D // self.num_heads
+        self.state_size = int(_cfg(c, "state_size", 8))
+        self.short_filter_length = int(_cfg(c, "short_filter_length", 3))
+        self.eps = float(_cfg(c, "eps", 1e-6))
+        mult = int(_cfg(c, "inner_size_multiple_of", 16))
+        inner = _cfg(c, "inner_mlp_size", None)
+        if inner is None:
+            inner = mult * ((int(2 * D * 4 / 3) + mult - 1) // mult)
+        self.inner_size = int(inner)
+        self.rotary_base = float(_cfg(c, "rotary_emb_base", 10000.0))
+        self.rotary_scaling = float(_cfg(c, "rotary_emb_scaling_factor", 1.0)) \
+            if bool(_cfg(c, "use_interpolated_rotary_pos_emb", False)) else 1.0
+        self.max_seqlen = int(_cfg(c, "max_seqlen", 8192))
+        if self.state_size != 8 or self.short_filter_length != 3:
+            raise ValueError("the gfx950 Hyena kernels are built for state_size 8 and short_filter_length 3")
+
+        bf = torch.bfloat16
+        self.embedding_layer = _Params(weight=((self.vocab_size, D), bf))
+        self.norm = _Params(scale=((D,), bf)) if bool(_cfg(c, "final_norm", True)) else None
+        self.unembed = nn.Module()
+        self.unembed.weight = self.embedding_layer.weight          # tied [REF evo/models.py:132-137]
+        blocks = []
+        for i in range(self.num_layers):
+            if i in self.attn_layer_idxs:
+                blocks.append(_AttentionBlock(D, self.inner_size, self.head_dim))
+            else:
+                blocks.append(_HyenaBlock(D, self.inner_size, self.state_size, self.short_filter_length))
+        self.blocks = nn.ModuleList(blocks)
+        self._ops = ops
+        self._packed = False
+        self._rot_cache: Dict[Tuple[int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    # ------------------------------------------------------------------ state-dict / dtype / device
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = True):
+        """Strict key/shape check, then ADOPT the given tensors (no 13 GB copy)."""
+        own = dict(self.named_parameters(remove_duplicate=False))
+        own.update(dict(self.named_buffers(remove_duplicate=False)))
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        if "unembed.weight" in missing and "embedding_layer.weight" in state_dict:
+            missing.remove("unembed.weight")
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for StripedHyena: missing keys {missing}, "
+                               f"unexpected keys {unexpected}")
+        for k, t in state_dict.items():
+            if k not in own or k == "unembed.weight":
+                continue
+            if tuple(own[k].shape) != tuple(t.shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(own[k].shape)}")
+            own[k].data = t.detach()
+        self._packed = False
+        self._rot_cache.clear()
+        from torch.nn.modules.module import _IncompatibleKeys
+        return _IncompatibleKeys(missing, unexpected)
+
+    def to_bfloat16_except_poles_residues(self):
+        """bf16 everywhere except the fp32 poles / residues (and inv_freq) [REF evo/models.py:148]."""
+        for k, p in self.named_parameters():
+            if k.endswith("poles") or k.endswith("residues"):
+                p.data = p.data.to(torch.float32)
+            else:
+                p.data = p.data.to(torch.bfloat16)
+        for _, b in self.named_buffers():
+            b.data = b.data.to(torch.float32)
+        self._packed = False
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._packed = False
+        self._rot_cache.clear()
+        return out
+
+    @property
+    def device(self):
+        return self.embedding_layer.weight.device
+
+    @property
+    def ops(self):
+        if self._ops is None:
+            from ..ops import default_ops
+            self._ops = default_ops()          # raises if the HIP library / GPU is unavailable
+        return self._ops
+
+    def _pack(self):
+        """Derived device-side layouts: fused [l1;l2] weight (one GEMM for the gated MLP), contiguous
+        [3D,3] FIR taps and [D,8,2] poles/residues.  l1/l2 keep their state-dict entries as views."""
+        for blk in self.blocks:
+            l1, l2 = blk.mlp.l1.weight, blk.mlp.l2.weight
+            w12 = torch.cat([l1.data, l2.data], dim=0).contiguous()
+            inner = l1.shape[0]
+            l1.data = w12[:inner]
+            l2.data = w12[inner:]
+            blk.mlp._w12 = w12
+            if isinstance(blk, _HyenaBlock):
+                f = blk.filter
+                D = self.hidden_size
+                f._fir_w = f.short_filter_weight.data.reshape(3 * D, self.short_filter_length).contiguous()
+                f._poles = f.poles.data.reshape(D, self.state_size, 2).float().contiguous()
+                f._residues = f.residues.data.reshape(D, self.state_size, 2).float().contiguous()
+        self._packed = True
+
+    # ------------------------------------------------------------------ caches
+    def initialize_inference_params(self):
+        """[REF evo/generation.py:116-120]"""
+        return {
+            "mha": InferenceParams(max_seqlen=self.max_seqlen, max_batch_size=1, seqlen_offset=0),
+            "hyena": RecurrentInferenceParams(fir_filter_length=self.short_filter_length,
+                                              state_dim=self.state_size, seqlen_offset=0),
+        }
+
+    def precompute_filters(self, L, device):
+        """Upstream materialises h[D,L] here; this engine never builds the filter (it is evaluated through
+        its modes on chip), so there is nothing to precompute.  Kept for API compatibility."""
+        return None
+
+    def _rotary(self, pos0: int, T: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos/sin [T, hd/2] f32 for absolute positions pos0..pos0+T-1: fp32 angles (positions divided by
+        the interpolation factor for the 131k model [REF evo-1-131k-base_inference.yml:39-40]) rounded to
+        bf16 values, as flash-attn caches them in the activation dtype."""
+        key = (pos0, T, str(device))
+        hit = self._rot_cache.get(key)
+        if hit is not None:
+            return hit
+        hd = self.head_dim
+        inv_freq = 1.0 / (self.rotary_base ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
+        t = torch.arange(pos0, pos0 + T, dtype=torch.float32, device=device)
+        if self.rotary_scaling != 1.0:
+            t = t / self.rotary_scaling
+        freqs = torch.outer(t, inv_freq)
+        cos = torch.cos(freqs).to(torch.bfloat16).float().contiguous()
+        sin = torch.sin(freqs).to(torch.bfloat16).float().contiguous()
+        if T > 1:                                  # decode steps are not worth caching
+            if len(self._rot_cache) > 8:
+                self._rot_cache.clear()
+            self._rot_cache[key] = (cos, sin)
+        return cos, sin
+
+    # ------------------------------------------------------------------ blocks
+    def _mlp_residual_(self, blk, x2d, bias):
+        ops = self.ops
+        n2 = ops.rmsnorm(x2d, bias, blk.post_norm.scale, self.eps)       # x += bias (in place); n2 = norm(x)
+        g = ops.linear(n2, blk.mlp._w12, None)
+        a = ops.gelu_gate(g)
+        ops.linear_residual_(x2d, a, blk.mlp.l3.weight)
+
+    def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams]):
+        ops = self.ops
+        D, H = self.hidden_size, self.num_heads
+        f = blk.filter
+        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
+        z = ops.linear(n1, blk.projections.weight, blk.projections.bias)          # [B*T, 3D]
+        have_state = cache is not None and i in cache.fir_state_dict
+        if have_state and T == 1:
+            y = ops.hyena_step(z, cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
+                               f._poles, f._residues, f.D, H)
+        else:
+            z3 = z.view(B, T, 3 * D)
+            halo = s0 = None
+            if have_state:                      # continue a cached prefix with more than one token
+                halo = cache.fir_state_dict[i].transpose(1, 2).contiguous()
+                s0 = cache.state_dict[i]
+            y3, state = ops.hyena_prefill(z3, f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H,
+                                          z_halo=halo, s0=s0, want_state=cache is not None)
+            y = y3.view(B * T, D)
+            if cache is not None:
+                K1 = self.short_filter_length - 1
+                tail = z3[:, -K1:, :]
+                if halo is not None and T < K1:
+                    tail = torch.cat([halo[:, T:], tail], dim=1)
+                elif T < K1:
+                    tail = torch.cat([z3.new_zeros(B, K1 - T, 3 * D), tail], dim=1)
+                cache.fir_state_dict[i] = tail.transpose(1, 2).contiguous()      # [B, 3D, 2]
+                cache.state_dict[i] = state
+        ops.linear_residual_(x2d, y, blk.out_filter_dense.weight)
+        self._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
+
+    def _kv_buffer(self, cache: InferenceParams, i: int, B: int, need: int, like: torch.Tensor):
+        H, hd = self.num_heads, self.head_dim
+        kv = cache.key_value_memory_dict.get(i)
+        cap_b = max(int(cache.max_batch_size or 1), B)
+        if kv is None or kv.shape[0] < B or kv.shape[1] < need or kv.device != like.device:
+            cap_t = max(int(cache.max_seqlen or 0), need)
+            if kv is not None and kv.shape[1] < need:
+                cap_t = max(cap_t, 2 * kv.shape[1])           # grow geometrically past max_seqlen (a20)
+            new = torch.zeros(cap_b, cap_t, 2, H, hd, dtype=like.dtype, device=like.device)
+            if kv is not None:
+                b0, t0 = min(kv.shape[0], cap_b), min(kv.shape[1], cap_t)
+                new[:b0, :t0] = kv[:b0, :t0].to(like.device)
+            cache.key_value_memory_dict[i] = kv = new
+        return kv
+
+    def _attn_block(self, i, blk, x2d, B, T, cache: Optional[InferenceParams]):
+        ops = self.ops
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        mha = blk.inner_mha_cls
+        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
+        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, T, 3, H, hd)
+        off = int(cache.seqlen_offset) if cache is not None else 0
+        cos, sin = self._rotary(off, T, x2d.device)
+        ops.rope_(qkv, cos, sin)
+        q = qkv[:, :, 0]
+        if cache is not None:
+            kv = self._kv_buffer(cache, i, B, off + T, qkv)
+            kv[:B, off:off + T].copy_(qkv[:, :, 1:3])
+            k = kv[:B, : off + T, 0]
+            v = kv[:B, : off + T, 1]
+        else:
+            k, v = qkv[:, :, 1], qkv[:, :, 2]
+        a = ops.attention(q, k, v, off).view(B * T, D)
+        ops.linear_residual_(x2d, a, mha.out_proj.weight)
+        self._mlp_residual_(blk, x2d, mha.out_proj.bias)
+
+    # ------------------------------------------------------------------ forward
+    def hidden_states(self, x: torch.Tensor, inference_params_dict=None) -> torch.Tensor:
+        """ids [B,T] -> final-norm hidden states [B*T, D] (logits = hidden @ E^T)."""
+        if not self._packed:
+            self._pack()
+        if x.dim() != 2:
+            raise ValueError("input_ids must be [batch, length]")
+        B, T = x.shape
+        ops = self.ops
+        h = ops.embed(x.to(self.device), self.embedding_layer.weight)             # [B*T, D]
+        mha_c = inference_params_dict["mha"] if inference_params_dict is not None else None
+        hy_c = inference_params_dict["hyena"] if inference_params_dict is not None else None
+        for i, blk in enumerate(self.blocks):
+            if isinstance(blk, _AttentionBlock):
+                self._attn_block(i, blk, h, B, T, mha_c)
+            else:
+                self._hyena_block(i, blk, h, B, T, hy_c)
+        if self.norm is not None:
+            h = ops.rmsnorm(h, None, self.norm.scale, self.eps)
+        return h
+
+    @torch.no_grad()
+    def forward(self, x, inference_params_dict=None, padding_mask=None):
+        """(logits [B,T,V] bf16, cache-or-None).  `padding_mask` is accepted for signature parity; evo never
+        passes it [REF evo/scoring.py:81; evo/generation.py:152-155] and pads are ordinary tokens."""
+        if padding_mask is not None:
+            raise NotImplementedError("padding_mask is not used on the evo path and is not supported")
+        B, T = x.shape
+        h = self.hidden_states(x, inference_params_dict)
+        logits = self.ops.linear(h, self.unembed.weight, None).view(B, T, self.vocab_size)
+        return logits, inference_params_dict
+
+    # upstream names, kept for callers that reach for them
+    def stateless_forward(self, x, padding_mask=None):
+        return self.forward(x, None, padding_mask)
+
+    def stateful_forward(self, x, inference_params_dict=None):
+        return self.forward(x, inference_params_dict)

@@ -1,0 +1,125 @@
+/* evo_mi355x.h -- C ABI of libevo_mi355x.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * StripedHyena forward that evo-design/evo runs through `stripedhyena==0.2.2` + FlashAttention-2.
+ *
+ * The reference has no C FFI: its plugin surface is the Python API of `stripedhyena` as consumed by
+ * `evo`.  Each entry point below replaces the vendor/third-party kernel(s) that the
+ * reference reaches for one step of that forward; the reference-side call site that pins the step is
+ * cited per function.  `evo_amd/ops.py` is the ctypes binding; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (every function):
+ *   - raw DEVICE pointers (tensor.data_ptr()); bf16 = uint16 storage; "c64" = interleaved {re,im} f32;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - no allocation, no host sync, no global state: safe to capture in a hipGraph; workspace is
+ *     passed in by the caller;
+ *   - return value is a hipError_t cast to int (0 = hipSuccess); -1 = bad argument.  The Python
+ *     binding raises on non-zero.
+ */
+#ifndef EVO_MI355X_H
+#define EVO_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI version; bumped when a signature changes. */
+int evo_abi_version(void);
+
+/* ---- embedding gather ------------------------------------------------------------------------
+ * replaces VocabParallelEmbedding.embed (ATen gather)    [REF evo/scoring.py:81; evo/models.py:136]
+ * ids [n_tok] int64, weight [vocab, D] bf16 -> out [n_tok, D] bf16.  ids outside [0,vocab) -> -1 is
+ * NOT checked on device; the host validates. */
+int evo_embed_bf16(const int64_t* ids, const void* weight, void* out,
+                   int64_t n_tok, int64_t D, int64_t vocab, void* stream);
+
+/* ---- RMSNorm -----------------------------------------------------------------------------------
+ * replaces the eager RMSNorm chain (norm, div, mul)      [REF evo/configs/evo-1-8k-base_inference.yml:13,31]
+ *   out = scale * x / (||x||_2 * D^-1/2 + eps)            (eps OUTSIDE the root)
+ * x [M, D] bf16 -> out [M, D] bf16, fp32 accumulation, single output rounding.
+ * If `bias` != NULL the row is first updated in place, x <- bf16(x + bias), and the norm is taken of
+ * the updated row (this folds the out_proj / out_filter_dense bias add and the residual write). */
+int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out,
+                     int64_t M, int64_t D, float eps, void* stream);
+
+/* ---- Hyena operator, parallel (prefill / scoring) form ------------------------------------------
+ * replaces HyenaInferenceEngine.parallel_fir + ParallelHyenaFilter.compute_filter + parallel_iir
+ * (+ prefill_via_modal_fft)                               [REF evo/configs/evo-1-8k-base_inference.yml:8,10,14,33,37;
+ *                                                          evo/generation.py:111-114]
+ * Three launches over a (batch, head, time-segment) decomposition; the long convolution
+ *   y_t = sum_{j<=t} h_{t-j} x1v_j,  h_k = Re sum_s R_s p_s^k
+ * is evaluated EXACTLY through its 8 complex modes (S_t = p S_{t-1} + x1v_t; y_t = Re sum R_s S_t),
+ * so no filter and no FFT buffer ever touches HBM.
+ *
+ *   z        [B, T, 3*D] bf16   projections output, channel-last; channel c = h*3*hd + g*hd + j,
+ *                               g in {0:x2, 1:x1, 2:v}  (column split, hd = D / n_heads = 128)
+ *   z_halo   [B, 2, 3*D] bf16 or NULL: rows t=-2,-1 (sequence-parallel halo; NULL = zeros)
+ *   fir_w    [3*D, 3] bf16      short_filter_weight (cross-correlation taps; tap 2 hits z_t)
+ *   fir_b    [3*D]    bf16      short_filter_bias
+ *   poles, residues [D, 8, 2] f32
+ *   dskip    [D] bf16           filter.D
+ *   seg_len                     time-segment length C (multiple of 4); n_seg = ceil(T / C)
+ *   agg      [B, n_seg, D, 8] c64 workspace:  (1) seg_state writes each segment's end state from a
+ *                               zero start; (2) carry_scan rewrites it in place into the state ENTERING
+ *                               each segment; (3) apply reads it.
+ *   s0       [B, D, 8] c64 or NULL: state entering t=0 (sequence-parallel carry-in / resumed prefill)
+ *   s_final  [B, D, 8] c64 or NULL: state after t=T-1  (== upstream prefill_via_modal_fft)
+ *   y        [B, T, D] bf16     (y_conv + x1v * dskip) * x2, channel-last
+ */
+int evo_hyena_seg_state(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
+                        const float* poles, float* agg,
+                        int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
+int evo_hyena_carry_scan(float* agg, const float* poles, const float* s0, float* s_final,
+                         int64_t B, int64_t T, int64_t D, int64_t seg_len, void* stream);
+int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
+                    const float* poles, const float* residues, const void* dskip,
+                    const float* agg, void* y,
+                    int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
+
+/* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
+ * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]
+ *   z_t [B, 3D] bf16; fir_state [B, 3D, 2] bf16 (in/out, oldest first); iir_state [B, D, 8] c64 (in/out)
+ *   y [B, D] bf16 */
+int evo_hyena_step(const void* z_t, void* fir_state, float* iir_state,
+                   const void* fir_w, const void* fir_b, const float* poles, const float* residues,
+                   const void* dskip, void* y, int64_t B, int64_t D, int64_t n_heads, void* stream);
+
+/* ---- rotary embedding -----------------------------------------------------------------------------
+ * replaces flash_attn's Triton rotary kernel               [REF evo/configs/evo-1-131k-base_inference.yml:39-40]
+ * NeoX (non-interleaved) pairs (i, i+hd/2), in place on the q and k thirds of a packed
+ * qkv [B, T, 3, H, hd] bf16.  cos/sin [T, hd/2] f32 are host-built for absolute positions
+ * pos0..pos0+T-1 (already divided by the interpolation factor, already rounded to bf16 values). */
+int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t,
+                     int64_t B, int64_t T, int64_t H, int64_t hd, void* stream);
+
+/* ---- causal multi-head attention forward ------------------------------------------------------------
+ * replaces flash_attn_2_cuda fwd / flash_attn_with_kvcache  [REF README.md:47-50; evo/configs/evo-1-8k-base_inference.yml:9,30]
+ * MFMA 32x32x16 bf16 tiles, online softmax in fp32, head dim 128 only.
+ *   q [B, Tq, H, 128], k/v [B, Tk, H, 128] bf16 with explicit element strides (batch, token, head);
+ *   o [B, Tq, H, 128] bf16 contiguous.  Query i may see key j iff j <= i + q_pos0 (q_pos0 = absolute
+ *   position of query 0 minus absolute position of key 0). */
+int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o,
+                             int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t q_pos0,
+                             int64_t q_sb, int64_t q_st, int64_t q_sh,
+                             int64_t k_sb, int64_t k_st, int64_t k_sh,
+                             int64_t v_sb, int64_t v_st, int64_t v_sh,
+                             float softmax_scale, void* stream);
+
+/* ---- gated MLP activation ---------------------------------------------------------------------------
+ * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]
+ * g [M, 2*I] bf16 = [l1 x | l2 x]  ->  a [M, I] bf16 = gelu_erf(g[:, :I]) * g[:, I:]. */
+int evo_gelu_gate_bf16(const void* g, void* a, int64_t M, int64_t I, void* stream);
+
+/* ---- scoring tail ---------------------------------------------------------------------------------------
+ * replaces torch.log_softmax + gather (+ entropy)            [REF evo/scoring.py:47-57,119-121]
+ * logits [M, V] bf16 (logits_f32 = 0) or f32 (logits_f32 = 1; evo.generation keeps its score buffer in
+ * f32 [REF evo/generation.py:97-103,287]), target [M] int64 (0 is written where target < 0 or >= V)
+ * -> logprob [M] f32 (may be NULL), entropy [M] f32 (may be NULL).  fp32 log-softmax. */
+int evo_logprob_entropy(const void* logits, int64_t logits_f32, const int64_t* target, float* logprob,
+                        float* entropy, int64_t M, int64_t V, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVO_MI355X_H */

@@ -1,0 +1,69 @@
+"""TEST INFRASTRUCTURE: an `ops` backend for evo_amd.sh.model.StripedHyena built on the CPU oracle
+(oracle/stripedhyena_ref.py).  It exists so the HOST logic (block sequencing, caches, generation loop,
+sequence-parallel exchange) can run in `-m "not gpu"` tests; the product never imports it."""
+import math
+
+import torch
+
+from oracle import stripedhyena_ref as R
+
+
+class OracleOps:
+    name = "oracle-cpu"
+
+    def __init__(self, act=torch.float64):
+        self.act = act              # dtype tensors are returned in (fp64: exact; bf16: rounding per op)
+
+    def _o(self, t):
+        return t.to(self.act)
+
+    def linear(self, x, w, b=None):
+        y = x.double() @ w.double().t()
+        if b is not None:
+            y = y + b.double()
+        return self._o(y)
+
+    def linear_residual_(self, res, x, w):
+        res.copy_(self._o(res.double() + x.double() @ w.double().t()))
+        return res
+
+    def embed(self, ids, weight):
+        return self._o(weight[ids.reshape(-1).long()])
+
+    def rmsnorm(self, x, bias, scale, eps):
+        xh, n = R.op_rmsnorm(x, scale, eps, bias)
+        if bias is not None:
+            x.copy_(self._o(xh))
+            xh, n = R.op_rmsnorm(x, scale, eps, None)
+        return self._o(n)
+
+    def hyena_prefill(self, z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo=None, s0=None,
+                      want_state=False, seg_len=None):
+        y, st = R.op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo, s0)
+        return self._o(y), (st.to(torch.complex64 if self.act != torch.float64 else torch.complex128)
+                            if want_state else None)
+
+    def hyena_end_state(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
+        D = z.shape[-1] // 3
+        _, st = R.op_hyena(z, fir_w, fir_b, poles, torch.zeros_like(poles), torch.zeros(D), n_heads, z_halo, None)
+        return st
+
+    def hyena_step(self, z_t, fir_state, iir_state, fir_w, fir_b, poles, residues, dskip, n_heads):
+        y, nf, ns = R.op_hyena_step(z_t, fir_state, iir_state, fir_w, fir_b, poles, residues, dskip, n_heads)
+        fir_state.copy_(nf.to(fir_state.dtype))
+        iir_state.copy_(ns.to(iir_state.dtype))
+        return self._o(y)
+
+    def rope_(self, qkv, cos, sin):
+        qkv.copy_(self._o(R.op_rope(qkv, cos, sin)))
+        return qkv
+
+    def attention(self, q, k, v, q_pos0):
+        return self._o(R.op_attention(q, k, v, q_pos0))
+
+    def gelu_gate(self, g):
+        return self._o(R.op_gelu_gate(g))
+
+    def logprob_entropy(self, logits, target, want_logprob=True, want_entropy=False):
+        lp, en = R.op_logprob_entropy(logits, target)
+        return (lp.float() if want_logprob and lp is not None else None), (en.float() if want_entropy else None)
