@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py -- forward-scoring throughput (nucleotides/s) of the MI355X-native StripedHyena engine.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json):
+  primary  `value`    : configs[1]  evo-1-8k-base scoring, batch 8 x 8,192 nt (T = 8,193 with BOS), bf16, per GPU.
+                        N > 1: every rank scores its own batch of 8 (independent sequences, no data-path
+                        collective) -> weak scaling.
+  secondary `ctx131k` : configs[2]/[3]  evo-1-131k-base scoring at 131,072 nt: batch 1 on one GPU; for N > 1
+                        batch N with the SEQUENCE sharded over the N ranks (RCCL all-gather of Hyena end states
+                        and of K/V, 2-row halo exchange) -- reported inside the same line.
+A step = one scoring pass (forward + log-prob reduction) over one resident batch of synthetic ACGT;
+tokenisation, weight creation and H2D copies are outside the timed region.  Weights are synthetic (real
+shapes, random init -- no checkpoint is reachable offline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def acgt_ids(batch, nt, seed0, device):
+    rows = []
+    for b in range(batch):
+        rng = np.random.default_rng(seed0 + b)
+        rows.append(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=nt))
+    ids = np.concatenate([np.zeros((batch, 1), np.int64), np.stack(rows).astype(np.int64)], axis=1)   # BOS
+    return torch.from_numpy(ids).to(device)
+
+
+def build_model(name, device, seed=0):
+    from evo_amd.models import _CONFIG_FOR, load_config
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.synthetic import synthetic_state_dict
+    m = StripedHyena(load_config(_CONFIG_FOR[name]))
+    m.load_state_dict(synthetic_state_dict(m, seed=seed, device=device), strict=True)
+    m.to_bfloat16_except_poles_residues()
+    return m.to(device)
+
+
+def scoring_step(model, ids):
+    """forward + per-token log-prob of the next token (what evo.scoring.score_sequences computes on device)."""
+    from evo_amd.scoring import logits_to_logprobs
+    logits, _ = model(ids)
+    return logits_to_logprobs(logits, ids, trim_bos=True)
+
+
+def timed(fn, steps, warmup, dist_on):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def flops_per_token(T):
+    """GEMM 12.889 GF + unembed 4.19 MF + causal attention 24,576*T."""
+    return 32 * 402_784_256 + 2 * 4096 * 512 + 24_576 * T
+
+
+def cpu_baseline(nt=512, layers=(0, 1, 2, 3)):
+    """The oracle (bf16-faithful mode, a 'port' of the reference forward) on the host cores: a 4-block slice
+    (3 Hyena + 1 attention) at full width on one 512-nt sequence, scaled x8 to the 32-block depth."""
+    from oracle import stripedhyena_ref as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = R.RefConfig(num_layers=4, attn_layer_idxs=(2,))
+    sd = R.make_synthetic_state_dict(cfg, 0)
+    m = R.RefStripedHyena(cfg, sd, "bf16")
+    ids = acgt_ids(1, nt, 1234, "cpu")
+    with torch.inference_mode():
+        m(ids)                                           # warm-up (thread pools, oneDNN primitives)
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 and time.perf_counter() - t0 < 20.0:
+            m(ids)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+    full = dt * (32 / 4)
+    return {"value": nt / full, "unit": "nt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle bf16 mode, 4 of 32 blocks (3 Hyena + 1 attention) at D=4096, 1 x {nt} nt, "
+                      f"{reps} reps, time x8 for full depth", "seconds_per_4_blocks": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--nt", type=int, default=8192)
+    ap.add_argument("--skip-131k", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--steps-131k", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    n_gpus = world
+
+    from evo_amd.ops import KernelTimer, default_ops
+    ops = default_ops()                                   # raises if libevo_mi355x.so / the GPU is missing
+
+    # ------------------------------------------------------------------ primary: 8 x 8,192 nt per GPU
+    model = build_model("evo-1-8k-base", device)
+    B, nt = args.batch, args.nt
+    ids = acgt_ids(B, nt, 1234 + 1000 * rank, device)
+    T = nt + 1
+    with torch.inference_mode():
+        dt = timed(lambda: scoring_step(model, ids), args.steps, args.warmup, dist_on)
+        # per-kernel HIP-event timings over a second, separately instrumented pass of the same steps
+        ops.timer = KernelTimer()
+        for _ in range(args.steps):
+            scoring_step(model, ids)
+        torch.cuda.synchronize()
+        ksum = ops.timer.summary()
+        ops.timer = None
+    ms_per_step = dt / args.steps * 1e3
+    value = n_gpus * B * nt / (dt / args.steps)
+
+    D = 4096
+    alg_bytes = B * T * (3 * D * 2 + D * 2)               # z in + y out per launch (32,768 B/token)
+    apply_ms = ksum["hyena_apply"][1]
+    op_ms = apply_ms + ksum["hyena_seg_state"][1] + ksum["hyena_carry_scan"][1]
+    achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
+    roofline = {"kernel": "hyena_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
+                "operator_3_launch_ms": op_ms, "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    attn_flops = B * 4 * D * T * T / 2                    # causal QK^T + PV per layer
+    kernels = {k: {"launches_per_step": v[0] // args.steps, "avg_ms": v[1]} for k, v in ksum.items()}
+    kernels["attn_fwd"]["tflops"] = attn_flops / (ksum["attn_fwd"][1] * 1e-3) / 1e12
+    kernels["attn_fwd"]["mfma_frac"] = kernels["attn_fwd"]["tflops"] / MFMA_BF16_PEAK_TFLOPS
+    gemm_ms = ksum["gemm"][1] * ksum["gemm"][0] / args.steps
+    out = {
+        "metric": "nucleotides/sec forward scoring, evo-1 7B", "value": value, "unit": "nt/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic ACGT, synthetic weights",
+        "config": {"workload": "evo-1-8k-base scoring, batch 8 x 8,192 nt per GPU (BASELINE configs[1])",
+                   "batch_per_gpu": B, "nt": nt, "tokens_per_seq": T,
+                   "parallelism": "independent batches per GPU" if n_gpus > 1 else "single GPU"},
+        "model_tflops": flops_per_token(T) * B * T / (dt / args.steps) / 1e12,
+        "roofline": roofline, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
+    }
+    del model
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ secondary: 131,072-nt context
+    if not args.skip_131k:
+        try:
+            out["ctx131k"] = bench_131k(args, device, rank, world, dist_on, ops)
+        except Exception as e:  # noqa: BLE001  (report, never hide)
+            out["ctx131k"] = {"error": f"{type(e).__name__}: {e}"}
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and n_gpus == 1 and not args.skip_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def bench_131k(args, device, rank, world, dist_on, ops):
+    from evo_amd.ops import KernelTimer
+    model = build_model("evo-1-131k-base", device)
+    nt = 131072
+    T = nt + 1
+    if world == 1:
+        ids = acgt_ids(1, nt, 4321, device)
+        fn = lambda: scoring_step(model, ids)             # noqa: E731
+        B = 1
+        par = "single GPU"
+    else:
+        from evo_amd.sp import SequenceParallelScorer
+        B = world
+        ids = acgt_ids(B, nt, 4321, device)               # every rank builds the same batch, keeps its shard
+        scorer = SequenceParallelScorer(model, rank, world)
+        fn = lambda: scorer.score_logprobs(ids)           # noqa: E731
+        par = f"sequence-parallel over {world} ranks (RCCL all-gather of states and K/V)"
+    with torch.inference_mode():
+        dt = timed(fn, args.steps_131k, 1, dist_on)
+        ops.timer = KernelTimer()
+        fn()
+        torch.cuda.synchronize()
+        ks = ops.timer.summary()
+        ops.timer = None
+    per = dt / args.steps_131k
+    D = 4096
+    Tl = T if world == 1 else (T + world - 1) // world
+    alg_bytes = B * Tl * (3 * D * 2 + D * 2)
+    apply_ms = ks["hyena_apply"][1]
+    op_ms = apply_ms + ks["hyena_seg_state"][1] + ks["hyena_carry_scan"][1]
+    res = {"value": B * nt / per, "unit": "nt/s", "ms_per_step": per * 1e3, "steps": args.steps_131k,
+           "config": {"workload": f"evo-1-131k-base scoring, batch {B} x 131,072 nt", "parallelism": par},
+           "model_tflops": flops_per_token(T) * B * T / per / 1e12,
+           "roofline": {"kernel": "hyena_apply_kernel", "bound": "hbm",
+                        "achieved": alg_bytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
+                        "operator_3_launch_ms": op_ms,
+                        "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "kernels": {k: {"launches": v[0], "avg_ms": v[1]} for k, v in ks.items()}}
+    if world == 1 and "attn_fwd" in ks:
+        fl = 4 * D * T * T / 2
+        res["kernels"]["attn_fwd"]["tflops"] = fl / (ks["attn_fwd"][1] * 1e-3) / 1e12
+        res["kernels"]["attn_fwd"]["mfma_frac"] = res["kernels"]["attn_fwd"]["tflops"] / MFMA_BF16_PEAK_TFLOPS
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
+if __name__ == "__main__":
+    main()

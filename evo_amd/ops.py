@@ -90,6 +90,45 @@ def pick_segment_length(B: int, T: int, H: int, target_waves: int = 8192) -> int
     return c
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches ON THE STREAM THEY ARE LAUNCHED ON (torch's current stream).
+    bench.py turns it on for the timed region to get per-kernel average durations for the roofline line."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    class _Span:
+        def __init__(self, timer, name):
+            self.timer, self.name = timer, name
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+        def __exit__(self, *exc):
+            self.b.record()
+            self.timer.pairs.setdefault(self.name, []).append((self.a, self.b))
+
+    def span(self, name):
+        return KernelTimer._Span(self, name)
+
+    def summary(self):
+        """{name: (launches, mean_ms)} -- call after a device synchronize."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.pairs.items()}
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
 class HipOps:
     """The gfx950 op set.  All tensors must live on the same ROCm device."""
 
@@ -100,6 +139,10 @@ class HipOps:
         if not torch.cuda.is_available():
             raise EvoLibraryError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.seg_len_override = int(os.environ.get("EVO_AMD_SEG_LEN", "0"))
+        self.timer: Optional[KernelTimer] = None
+
+    def _t(self, name):
+        return self.timer.span(name) if self.timer is not None else _NOSPAN
 
     # ---- plumbing -------------------------------------------------------------------------------
     @staticmethod
@@ -114,13 +157,15 @@ class HipOps:
     # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16."""
-        if b is not None:
-            return torch.addmm(b, x, w.t())
-        return torch.mm(x, w.t())
+        with self._t("gemm"):
+            if b is not None:
+                return torch.addmm(b, x, w.t())
+            return torch.mm(x, w.t())
 
     def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         """res += x @ w^T (fp32 accumulate, one rounding), in place."""
-        return res.addmm_(x, w.t())
+        with self._t("gemm"):
+            return res.addmm_(x, w.t())
 
     # ---- kernels -------------------------------------------------------------------------------------
     def embed(self, ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -141,8 +186,9 @@ class HipOps:
             self._need(bias, torch.bfloat16, "rmsnorm bias")
         M, D = x.shape
         out = torch.empty_like(x)
-        _check(self.lib.evo_rmsnorm_bf16(x.data_ptr(), _ptr(bias), scale.data_ptr(), out.data_ptr(), M, D,
-                                         float(eps), _stream()), "evo_rmsnorm_bf16")
+        with self._t("rmsnorm_bias" if bias is not None else "rmsnorm"):
+            _check(self.lib.evo_rmsnorm_bf16(x.data_ptr(), _ptr(bias), scale.data_ptr(), out.data_ptr(), M, D,
+                                             float(eps), _stream()), "evo_rmsnorm_bf16")
         return out
 
     def hyena_prefill(self, z: torch.Tensor, fir_w: torch.Tensor, fir_b: torch.Tensor, poles: torch.Tensor,
@@ -171,14 +217,17 @@ class HipOps:
         y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
         s_final = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device) if want_state else None
         st = _stream()
-        _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                            poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
-               "evo_hyena_seg_state")
-        _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), _ptr(s0r), _ptr(s_final), B, T, D, C,
-                                             st), "evo_hyena_carry_scan")
-        _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                        poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
-                                        y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
+        with self._t("hyena_seg_state"):
+            _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                                poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+                   "evo_hyena_seg_state")
+        with self._t("hyena_carry_scan"):
+            _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), _ptr(s0r), _ptr(s_final), B, T, D,
+                                                 C, st), "evo_hyena_carry_scan")
+        with self._t("hyena_apply"):
+            _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                            poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
+                                            y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
         state = torch.view_as_complex(s_final) if want_state else None
         return y, state
 
@@ -235,17 +284,20 @@ class HipOps:
         if hd != 128:
             raise RuntimeError("attention: head dim must be 128")
         o = torch.empty(B, Tq, H, hd, dtype=torch.bfloat16, device=q.device)
-        _check(self.lib.evo_attn_fwd_causal_bf16(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
-            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-            v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _stream()), "evo_attn_fwd_causal_bf16")
+        with self._t("attn_fwd"):
+            _check(self.lib.evo_attn_fwd_causal_bf16(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
+                q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _stream()), "evo_attn_fwd_causal_bf16")
         return o
 
     def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:
         self._need(g, torch.bfloat16, "gelu_gate g")
         M, I2 = g.shape
         a = torch.empty(M, I2 // 2, dtype=torch.bfloat16, device=g.device)
-        _check(self.lib.evo_gelu_gate_bf16(g.data_ptr(), a.data_ptr(), M, I2 // 2, _stream()), "evo_gelu_gate_bf16")
+        with self._t("gelu_gate"):
+            _check(self.lib.evo_gelu_gate_bf16(g.data_ptr(), a.data_ptr(), M, I2 // 2, _stream()),
+                   "evo_gelu_gate_bf16")
         return a
 
     def logprob_entropy(self, logits: torch.Tensor, target: Optional[torch.Tensor], want_logprob=True,

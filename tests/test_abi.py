@@ -1,0 +1,57 @@
+"""CPU: the C-ABI shared library builds, loads, and exports every symbol include/evo_mi355x.h declares;
+the ctypes table in evo_amd/ops.py covers exactly that set; the product path refuses to run without a GPU
+instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from evo_amd import _build
+from evo_amd import ops as evo_ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "evo_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(evo_\w+)\s*\(", text)))
+
+
+def test_header_table_and_exports_agree():
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    assert sorted(_build.EXPORTS) == declared
+    assert sorted(evo_ops._SIGNATURES) == declared
+
+
+def test_library_builds_and_exports_every_symbol():
+    path = _build.build()
+    lib = ctypes.CDLL(str(path))
+    for name in _declared():
+        assert hasattr(lib, name), name
+    lib.evo_abi_version.restype = ctypes.c_int
+    assert lib.evo_abi_version() == 1
+    assert evo_ops.load_library() is not None
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = evo_ops.load_library()
+    # bad shapes are rejected on the host before any launch
+    assert lib.evo_rmsnorm_bf16(None, None, None, None, 4, 7, 1e-6, None) == -1
+    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, 1, 16, 256, 3, 64, None) == -1
+    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, 1, 16, 256, 2, 6, None) == -1
+    assert lib.evo_gelu_gate_bf16(None, None, 4, 12, None) == -1
+    assert lib.evo_attn_fwd_causal_bf16(None, None, None, None, 1, 1, 4, 4, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    from evo_amd.sh.model import StripedHyena
+    with pytest.raises(evo_ops.EvoLibraryError):
+        evo_ops.HipOps()
+    m = StripedHyena(dict(hidden_size=128, num_layers=1, attn_layer_idxs=[], num_attention_heads=1))
+    with pytest.raises(evo_ops.EvoLibraryError):
+        m(torch.zeros(1, 4, dtype=torch.long))

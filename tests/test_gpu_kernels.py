@@ -1,0 +1,258 @@
+"""GPU (-m gpu): every C-ABI kernel against the fp64 op-level oracle on the same seeded bf16 inputs.
+
+Tolerances (floating point, stated per SURVEY.md 8c): outputs are bf16, so one output rounding costs
+<= 2^-9 relative per element (rel-L2 ~ 1.1e-3).  Kernels that accumulate in fp32 from exact bf16 inputs
+must stay within rel-L2 2e-3 and |err| <= 2^-8*|ref| + atol; attention additionally rounds P to bf16
+before P.V (FlashAttention-2 numerics) and gets rel-L2 4e-3.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import stripedhyena_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from evo_amd.ops import HipOps
+    return HipOps()
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_l2(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def assert_close_bf16(got, ref, rl2=2e-3, atol=None):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert torch.isfinite(got).all()
+    atol = float(ref.abs().max()) * 2e-3 if atol is None else atol
+    err = (got - ref).abs()
+    bound = ref.abs() * 2 ** -8 + atol
+    assert (err <= bound).all(), f"max excess {(err - bound).max().item():.3e}"
+    assert rel_l2(got, ref) < rl2, rel_l2(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_embed(ops):
+    w = bf(torch.randn(512, 256, generator=gen(0)))
+    ids = torch.randint(0, 512, (3, 17), generator=gen(1))
+    out = ops.embed(ids.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), w[ids.reshape(-1)])          # bit exact gather
+
+
+@pytest.mark.parametrize("M,D", [(5, 256), (37, 4096), (3, 1024), (2, 8192)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_rmsnorm(ops, M, D, with_bias):
+    x = bf(torch.randn(M, D, generator=gen(2)) * 3)
+    scale = bf(1 + 0.1 * torch.randn(D, generator=gen(3)))
+    bias = bf(torch.randn(D, generator=gen(4))) if with_bias else None
+    xd = x.to(DEV).clone()
+    out = ops.rmsnorm(xd, bias.to(DEV) if with_bias else None, scale.to(DEV), 1e-6)
+    if with_bias:
+        x_new = bf(x.double() + bias.double())
+        assert torch.equal(xd.cpu(), x_new)                     # in-place residual write, RNE
+        _, ref = R.op_rmsnorm(x_new, scale, 1e-6)
+    else:
+        assert torch.equal(xd.cpu(), x)
+        _, ref = R.op_rmsnorm(x, scale, 1e-6)
+    assert_close_bf16(out, ref)
+
+
+def test_rmsnorm_zero_row_uses_eps(ops):
+    x = torch.zeros(2, 256, dtype=torch.bfloat16)
+    out = ops.rmsnorm(x.to(DEV), None, torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-6)
+    assert torch.equal(out.cpu(), x)
+
+
+@pytest.mark.parametrize("B,T,H,hd,scaling", [(2, 19, 2, 128, 1.0), (1, 300, 4, 128, 16.0), (1, 5, 1, 64, 1.0)])
+def test_rope(ops, B, T, H, hd, scaling):
+    qkv = bf(torch.randn(B, T, 3, H, hd, generator=gen(5)))
+    t = torch.arange(7, 7 + T, dtype=torch.float32) / scaling
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.outer(t, inv)
+    cos, sin = torch.cos(fr).bfloat16().float(), torch.sin(fr).bfloat16().float()
+    ref = R.op_rope(qkv, cos, sin)
+    got = ops.rope_(qkv.to(DEV).clone(), cos.to(DEV), sin.to(DEV))
+    assert torch.equal(got[:, :, 2].cpu(), qkv[:, :, 2])        # v untouched
+    assert_close_bf16(got, ref)
+
+
+@pytest.mark.parametrize("M,I", [(7, 64), (33, 10928)])
+def test_gelu_gate(ops, M, I):
+    g = bf(torch.randn(M, 2 * I, generator=gen(6)) * 2)
+    assert_close_bf16(ops.gelu_gate(g.to(DEV)), R.op_gelu_gate(g))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_logprob_entropy(ops, dtype):
+    logits = (torch.randn(41, 512, generator=gen(7)) * 4).to(dtype)
+    tgt = torch.randint(0, 512, (41,), generator=gen(8))
+    tgt[3] = -1
+    lp, en = ops.logprob_entropy(logits.to(DEV), tgt.to(DEV), want_logprob=True, want_entropy=True)
+    rlp, ren = R.op_logprob_entropy(logits, tgt)
+    assert (lp.double().cpu() - rlp).abs().max() < 2e-5 * 20
+    assert (en.double().cpu() - ren).abs().max() < 1e-4
+    assert lp[3].item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ Hyena operator
+def hyena_params(D, seed):
+    g = gen(seed)
+    fir_w = bf(torch.randn(3 * D, 3, generator=g) * 0.3)
+    fir_b = bf(torch.randn(3 * D, generator=g) * 0.1)
+    u = torch.rand(D, 8, generator=g)
+    one_minus = 10.0 ** (-5.0 + 4.0 * u)
+    mag, ang = 1.0 - one_minus, (torch.rand(D, 8, generator=g) * 2 - 1) * math.pi
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous()
+    res = (torch.randn(D, 8, 2, generator=g) * 0.25 * torch.sqrt(one_minus).unsqueeze(-1) * 4).float().contiguous()
+    dskip = bf(torch.randn(D, generator=g) * 0.5)
+    return fir_w, fir_b, poles, res, dskip
+
+
+def run_hyena(ops, z, prm, H, **kw):
+    fir_w, fir_b, poles, res, dskip = prm
+    d = lambda t: None if t is None else t.to(DEV)
+    kw = {k: (d(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    return ops.hyena_prefill(z.to(DEV), d(fir_w), d(fir_b), d(poles), d(res), d(dskip), H, **kw)
+
+
+@pytest.mark.parametrize("B,T,D,H,seg", [
+    (2, 37, 256, 2, 8),          # ragged last segment, scalar tail
+    (1, 1, 128, 1, 64),          # single token
+    (2, 3, 128, 1, 4),           # shorter than one unrolled group
+    (1, 513, 4096, 32, 64),      # BASELINE configs[0] length at the real width
+    (2, 8193, 256, 2, 512),      # BASELINE configs[1] length (T = nt + 1 is odd)
+    (1, 8193, 256, 2, None),     # default segment heuristic
+])
+def test_hyena_prefill_matches_oracle(ops, B, T, D, H, seg):
+    prm = hyena_params(D, 10)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(11)))
+    y, st = run_hyena(ops, z, prm, H, want_state=True, seg_len=seg)
+    ry, rst = R.op_hyena(z, *prm, H)
+    assert_close_bf16(y, ry)
+    assert (st.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max()
+
+
+def test_hyena_prefill_131k_long_memory(ops):
+    """BASELINE configs[2] length: T = 131,073 with |p| up to 0.99999.  One head (128 channels) keeps the fp64
+    oracle affordable; the segment/carry machinery is independent of the head count."""
+    B, T, D, H = 1, 131073, 128, 1
+    prm = hyena_params(D, 12)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(13)))
+    y, st = run_hyena(ops, z, prm, H, want_state=True, seg_len=512)
+    ry, rst = R.op_hyena(z, *prm, H)
+    assert_close_bf16(y, ry)
+    assert (st.cpu().to(torch.complex128) - rst).abs().max() <= 1e-4 * rst.abs().max()
+    # a different segmentation must give the same function (size-independent property)
+    y2, _ = run_hyena(ops, z, prm, H, seg_len=1024)
+    assert rel_l2(y2, y) < 2e-3
+
+
+def test_hyena_prefill_linearity_in_v_at_full_size(ops):
+    """Full width, T = 8,193: scaling the v third by 2 scales x1v (minus bias terms) -- checked through the
+    exact identity  op(z; b=0) is degree-1 in v: y(2v) = 2 y(v)  when FIR biases are zero."""
+    B, T, D, H = 1, 8193, 4096, 32
+    fir_w, fir_b, poles, res, dskip = hyena_params(D, 14)
+    prm = (fir_w, torch.zeros_like(fir_b), poles, res, dskip)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(15)))
+    z2 = z.clone().view(B, T, H, 3, 128)
+    z2[:, :, :, 2] = z2[:, :, :, 2] * 2                      # exact in bf16
+    y1, _ = run_hyena(ops, z, prm, H)
+    y2, _ = run_hyena(ops, z2.view(B, T, 3 * D), prm, H)
+    assert rel_l2(y2, 2 * y1.double()) < 2.5e-3
+
+
+def test_hyena_prefill_split_with_halo_and_state(ops):
+    B, T, D, H = 2, 300, 256, 2
+    prm = hyena_params(D, 16)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(17)))
+    y, st = run_hyena(ops, z, prm, H, want_state=True, seg_len=32)
+    ya, sa = run_hyena(ops, z[:, :131].contiguous(), prm, H, want_state=True, seg_len=32)
+    yb, sb = run_hyena(ops, z[:, 131:].contiguous(), prm, H, want_state=True, seg_len=16,
+                       z_halo=z[:, 129:131].contiguous(), s0=sa)
+    ry, rst = R.op_hyena(z, *prm, H)
+    assert_close_bf16(torch.cat([ya, yb], 1), ry)
+    assert (sb.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max()
+
+
+def test_hyena_step_matches_oracle_and_prefill(ops):
+    B, T, D, H = 3, 40, 256, 2
+    prm = hyena_params(D, 18)
+    fir_w, fir_b, poles, res, dskip = prm
+    z = bf(torch.randn(B, T + 5, 3 * D, generator=gen(19)))
+    _, st = run_hyena(ops, z[:, :T].contiguous(), prm, H, want_state=True, seg_len=8)
+    fir_state = z[:, T - 2:T].transpose(1, 2).contiguous().to(DEV)
+    r_fs, r_st = fir_state.cpu(), st.cpu().to(torch.complex128)
+    ry_full, _ = R.op_hyena(z, *prm, H)
+    for k in range(5):
+        y = ops.hyena_step(z[:, T + k].contiguous().to(DEV), fir_state, st, fir_w.to(DEV), fir_b.to(DEV),
+                           poles.to(DEV), res.to(DEV), dskip.to(DEV), H)
+        ry, r_fs, r_st = R.op_hyena_step(z[:, T + k], r_fs, r_st, *prm, H)
+        assert_close_bf16(y, ry)
+        assert_close_bf16(y, ry_full[:, T + k], rl2=3e-3)
+        assert torch.equal(fir_state.cpu(), r_fs.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,Tq,Tk,off", [
+    (2, 2, 37, 37, 0),            # one ragged tile
+    (1, 2, 513, 513, 0),          # BASELINE configs[0] length
+    (1, 1, 128, 128, 0),          # exactly one query block / two key tiles
+    (1, 2, 1000, 1000, 0),
+    (2, 2, 1, 300, 299),          # decode against a KV cache
+    (1, 2, 64, 200, 136),         # chunk continuation
+    (1, 1, 130, 700, 570),        # sequence-parallel shard: local queries, gathered keys
+])
+def test_attention_matches_oracle(ops, B, H, Tq, Tk, off):
+    q = bf(torch.randn(B, Tq, H, 128, generator=gen(20)))
+    k = bf(torch.randn(B, Tk, H, 128, generator=gen(21)))
+    v = bf(torch.randn(B, Tk, H, 128, generator=gen(22)))
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), off)
+    assert_close_bf16(o, R.op_attention(q, k, v, off), rl2=4e-3, atol=2e-2)
+
+
+def test_attention_packed_qkv_views_and_kv_cache_layout(ops):
+    B, T, H = 2, 257, 2
+    qkv = bf(torch.randn(B, T, 3, H, 128, generator=gen(23))).to(DEV)
+    o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+    ref = R.op_attention(qkv[:, :, 0].cpu(), qkv[:, :, 1].cpu(), qkv[:, :, 2].cpu(), 0)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
+    kv = torch.full((B, 400, 2, H, 128), float("nan"), dtype=torch.bfloat16, device=DEV)   # poison past the end
+    kv[:, :T] = qkv[:, :, 1:3]
+    o2 = ops.attention(qkv[:, :, 0], kv[:, :T, 0], kv[:, :T, 1], 0)
+    assert torch.equal(o2, o)
+
+
+def test_attention_outlier_scores(ops):
+    """Large score outliers late in the key range force big running-max jumps (the rescale path)."""
+    B, H, T = 1, 1, 384
+    q = bf(torch.randn(B, T, H, 128, generator=gen(24)))
+    k = bf(torch.randn(B, T, H, 128, generator=gen(25)))
+    v = bf(torch.randn(B, T, H, 128, generator=gen(26)))
+    k[0, 200, 0] = q[0, 300, 0] * 3       # key 200 dominates query 300 (and nearby rows see a huge score)
+    k[0, 70, 0] = q[0, 90, 0] * 2
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
+    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+
+
+def test_attention_4k_causal(ops):
+    B, H, T = 1, 2, 4099
+    q = bf(torch.randn(B, T, H, 128, generator=gen(27)))
+    k = bf(torch.randn(B, T, H, 128, generator=gen(28)))
+    v = bf(torch.randn(B, T, H, 128, generator=gen(29)))
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
+    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)

@@ -1,0 +1,112 @@
+"""CPU: the oracle is self-consistent -- FFT long conv == direct causal conv == modal
+recurrence; prefill state == recurrence state; cached decoding == full forward; the op-level functions
+agree with the model-level restatement and compose across a time split (halo + carried state)."""
+import math
+
+import pytest
+import torch
+
+from oracle import stripedhyena_ref as R
+
+CFG = dict(vocab_size=512, hidden_size=64, num_layers=4, attn_layer_idxs=[2], num_attention_heads=4)
+
+
+def _model(mode="fp64", **over):
+    cfg = R.RefConfig.from_dict({**CFG, **over})
+    sd = R.make_synthetic_state_dict(cfg, 0)
+    return cfg, sd, R.RefStripedHyena(cfg, sd, mode)
+
+
+def test_inner_size_and_param_count():
+    cfg = R.RefConfig()
+    assert cfg.inner_size == 10928 and cfg.head_dim == 128 and len(cfg.hyena_layer_idxs) == 29
+    D, I = 4096, 10928
+    hy = D * 3 * D + 3 * D + D * D + D + 3 * D * I + 2 * D + D + 3 * D * 3 + 3 * D + D * 8 * 2 * 2
+    at = D * 3 * D + 3 * D + D * D + D + 3 * D * I + 2 * D + 64      # + inv_freq buffer
+    assert hy == 201_601_024 and at == 201_416_768
+    assert 29 * hy + 3 * at + 512 * D + D == 6_452_781_248
+
+
+def test_fft_direct_recurrence_agree():
+    torch.manual_seed(0)
+    _, sd, m = _model()
+    pre = "blocks.0."
+    x = torch.randn(2, 64, 37, dtype=torch.float64)
+    h = m.compute_filter(pre, 37)
+    y_fft = m.fftconv(x, h)
+    y_dir = R.direct_causal_conv(x, h)
+    p, r = m.poles_residues(pre)
+    y_rec, S = R.modal_recurrence(x, p, r)
+    assert (y_fft - y_dir).abs().max() < 1e-10
+    assert (y_fft - y_rec).abs().max() < 1e-10
+    assert (m.prefill_state_recurrence(x, pre) - S).abs().max() < 1e-10
+
+
+def test_cached_decode_matches_full_forward():
+    _, _, m = _model()
+    ids = torch.randint(0, 512, (2, 29), generator=torch.Generator().manual_seed(1))
+    full, none = m(ids)
+    assert none is None
+    c = m.initialize_inference_params()
+    c["mha"].max_batch_size = 2
+    l0, c = m(ids[:, :11], c)
+    assert (l0 - full[:, :11]).abs().max() < 1e-10
+    for t in range(11, 29):
+        c["mha"].seqlen_offset = c["hyena"].seqlen_offset = t
+        lt, c = m(ids[:, t:t + 1], c)
+        assert (lt[:, 0] - full[:, t]).abs().max() < 1e-9
+
+
+def test_modes_order():
+    ids = torch.randint(0, 512, (1, 33), generator=torch.Generator().manual_seed(2))
+    ref = _model("fp64")[2](ids)[0]
+    e32 = ((_model("fp32")[2](ids)[0].double() - ref).norm() / ref.norm()).item()
+    e16 = ((_model("bf16")[2](ids)[0].double() - ref).norm() / ref.norm()).item()
+    assert e32 < 1e-5 < e16 < 5e-2
+
+
+def test_rotary_interpolation_divides_positions():
+    _, _, m8 = _model()
+    _, _, m131 = _model(use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+    c8, _ = m8.rotary_table(0, 64)
+    c131, _ = m131.rotary_table(0, 64)
+    assert torch.equal(c131[16], c8[1]) and torch.equal(c131[32], c8[2])
+
+
+def test_op_hyena_matches_model_filter_and_splits_in_time():
+    cfg, sd, m = _model()
+    pre = "blocks.0."
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 41, 3 * 64, generator=g, dtype=torch.float64)
+    y_model, st_model = m.hyena_filter_parallel(z, pre, want_state=True)
+    args = (sd[pre + "filter.short_filter_weight"].double()[:, 0], sd[pre + "filter.short_filter_bias"].double(),
+            sd[pre + "filter.poles"].double().reshape(64, 8, 2), sd[pre + "filter.residues"].double().reshape(64, 8, 2),
+            sd[pre + "filter.D"].double(), 4)
+    y, st = R.op_hyena(z, *args)
+    assert (y - y_model).abs().max() < 1e-10 and (st - st_model).abs().max() < 1e-10
+    # split at t=17: second half sees a 2-row halo and the carried state
+    ya, sa = R.op_hyena(z[:, :17], *args)
+    yb, sb = R.op_hyena(z[:, 17:], *args, z_halo=z[:, 15:17], s0=sa)
+    assert (torch.cat([ya, yb], 1) - y).abs().max() < 1e-10 and (sb - st).abs().max() < 1e-10
+    # and one recurrent step continues it
+    y1, nf, ns = R.op_hyena_step(z[:, 40], z[:, 38:40].transpose(1, 2), R.op_hyena(z[:, :40], *args)[1], *args)
+    assert (y1 - y[:, 40]).abs().max() < 1e-10 and (ns - st).abs().max() < 1e-10
+
+
+def test_op_attention_offsets():
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(1, 9, 2, 16, generator=g, dtype=torch.float64)
+    k = torch.randn(1, 9, 2, 16, generator=g, dtype=torch.float64)
+    v = torch.randn(1, 9, 2, 16, generator=g, dtype=torch.float64)
+    full = R.op_attention(q, k, v, 0)
+    tail = R.op_attention(q[:, 5:], k, v, 5)
+    assert (tail - full[:, 5:]).abs().max() < 1e-12
+    assert (full[:, 0] - v[:, 0]).abs().max() < 1e-12          # first query sees only key 0
+
+
+def test_sample_greedy_and_topk():
+    logits = torch.tensor([[0.1, 3.0, 2.0, -1.0], [5.0, 1.0, 0.0, 4.9]])
+    assert R.sample(logits, top_k=1).tolist() == [1, 0]
+    g = torch.Generator().manual_seed(0)
+    draws = {int(R.sample(logits[:1], top_k=2, temperature=1.0, generator=g)) for _ in range(50)}
+    assert draws <= {1, 2}
