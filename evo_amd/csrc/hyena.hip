@@ -216,6 +216,31 @@ __global__ __launch_bounds__(256) void hyena_carry_scan_kernel(float2* __restric
     }
 }
 
+// sequence-parallel fix-up: `agg` already holds the entering states for a ZERO carry-in; add the
+// contribution p^(k*C) * s0 of the state s0 that enters this shard (known only after the all-gather).
+__global__ __launch_bounds__(256) void hyena_carry_add_kernel(float2* __restrict__ agg, const float2* __restrict__ poles,
+                                                              const float2* __restrict__ s0, int B, int D, int C,
+                                                              int n_seg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_b = (int64_t)D * NS;
+    if (i >= (int64_t)B * per_b) return;
+    const int b = (int)(i / per_b);
+    const int64_t ds = i - (int64_t)b * per_b;
+    const float2 p = poles[ds];
+    double pcr, pci;
+    cpow_int((double)p.x, (double)p.y, C, pcr, pci);
+    const float2 v0 = s0[i];
+    double cr = v0.x, ci = v0.y;
+    float2* a = agg + (int64_t)b * n_seg * per_b + ds;
+    for (int k = 0; k < n_seg; ++k) {
+        float2 v = a[(int64_t)k * per_b];
+        a[(int64_t)k * per_b] = make_float2(v.x + (float)cr, v.y + (float)ci);
+        double nr = pcr * cr - pci * ci;
+        ci = pcr * ci + pci * cr;
+        cr = nr;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launch 3
 __global__ __launch_bounds__(256, 2) void hyena_apply_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
@@ -420,6 +445,16 @@ extern "C" int evo_hyena_carry_scan(float* agg, const float* poles, const float*
     hipLaunchKernelGGL(hyena_carry_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (float2*)agg, (const float2*)poles, (const float2*)s0, (float2*)s_final, (int)B, T, (int)D,
                        (int)seg_len, n_seg);
+    return evo_launch_status();
+}
+
+extern "C" int evo_hyena_carry_add(float* agg, const float* poles, const float* s0, int64_t B, int64_t T, int64_t D,
+                                   int64_t seg_len, void* stream) {
+    if (B <= 0 || T <= 0 || D <= 0 || seg_len <= 0 || !s0) return -1;
+    const int n_seg = (int)((T + seg_len - 1) / seg_len);
+    const int64_t n = B * D * NS;
+    hipLaunchKernelGGL(hyena_carry_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float2*)agg, (const float2*)poles, (const float2*)s0, (int)B, (int)D, (int)seg_len, n_seg);
     return evo_launch_status();
 }
 

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "evo_rmsnorm_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _PTR], _c.c_int),
     "evo_hyena_seg_state": ([_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_carry_scan": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_hyena_carry_add": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_apply": ([_PTR] * 9 + [_I64] * 5 + [_PTR], _c.c_int),
     "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
@@ -230,6 +231,43 @@ class HipOps:
                                             y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
         state = torch.view_as_complex(s_final) if want_state else None
         return y, state
+
+    # The same operator in two stages, for sequence parallelism: stage 1 (launches 1+2) yields the shard's end
+    # state from a ZERO carry-in; after the ranks exchange those, stage 2 (carry-add + launch 3) finishes.
+    def hyena_stage1(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
+        self._need(z, torch.bfloat16, "hyena z")
+        B, T, D3 = z.shape
+        D = D3 // 3
+        C = seg_len or self.seg_len_override or pick_segment_length(B, T, n_heads)
+        n_seg = (T + C - 1) // C
+        agg = torch.empty(B, n_seg, D, 8, 2, dtype=torch.float32, device=z.device)
+        s_end = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
+        st = _stream()
+        with self._t("hyena_seg_state"):
+            _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                                poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+                   "evo_hyena_seg_state")
+        with self._t("hyena_carry_scan"):
+            _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), None, s_end.data_ptr(), B, T, D, C,
+                                                 st), "evo_hyena_carry_scan")
+        return (agg, C), torch.view_as_complex(s_end)
+
+    def hyena_stage2(self, z, fir_w, fir_b, poles, residues, dskip, n_heads, stage1, z_halo=None, s0=None):
+        agg, C = stage1
+        B, T, D3 = z.shape
+        D = D3 // 3
+        st = _stream()
+        if s0 is not None:
+            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
+            with self._t("hyena_carry_add"):
+                _check(self.lib.evo_hyena_carry_add(agg.data_ptr(), poles.data_ptr(), s0r.data_ptr(), B, T, D, C, st),
+                       "evo_hyena_carry_add")
+        y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
+        with self._t("hyena_apply"):
+            _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                            poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
+                                            y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
+        return y
 
     def hyena_end_state(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
         """State after the last token of z from a ZERO entering state (sequence-parallel pass 1)."""

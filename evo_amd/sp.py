@@ -1,0 +1,182 @@
+"""Sequence-parallel scoring: the token dimension of every sequence is cut into R contiguous shards, one per
+GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI).  The reference has no
+multi-GPU path at all, so this is new design, not a translation.
+
+Rank r owns tokens [r*Tl, min(T, (r+1)*Tl)), Tl = ceil(T/R), of ALL batch rows.  Embedding, RMSNorm, every
+GEMM, the MLP, the unembedding and the scoring tail are token-local -> no communication.  Per layer:
+
+  Hyena block   (1) 2-row halo of z from the previous rank (for the k=3 FIR)        all-gather of [B,2,3D] tails
+                (2) stage 1 on the shard (zero carry-in) -> end state E_r [B,D,8] c64
+                (3) all-gather of the R end states (262 KB * B per rank: latency-, not bandwidth-bound)
+                (4) S_in(r) = sum_{q<r} p^{Tl*(r-1-q)} E_q   (exact: the filter is a finite sum of modes)
+                (5) stage 2: carry-add + apply kernel
+  Attention     K,V of the shard are all-gathered (token-major layout so the gathered buffer is directly
+                addressable by the attention kernel's strides); queries attend keys <= their position.  The
+                gathers are issued per batch row and asynchronously, so row b's attention overlaps the
+                transfers of rows b+1.. on the collective stream.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the per-layer volumes above are 1.88 GB*B of K/V per
+attention layer (3 of 32 layers) and < 0.4 MB*B per Hyena layer.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .sh.model import StripedHyena, _AttentionBlock
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class DistComm:
+    """all-gather over torch.distributed (RCCL when the backend is "nccl"; gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def all_gather(self, t: torch.Tensor, async_op: bool = False):
+        """Equal-shaped tensors from every rank, stacked on a new leading dim -> ([R, *shape], work)."""
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if dist.get_backend(self.group) == "nccl":
+            w = dist.all_gather_into_tensor(out.view(self.world * t.shape[0], *t.shape[1:]), t, group=self.group,
+                                            async_op=async_op)
+        else:
+            w = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=async_op)
+        return out, (w if async_op else _Done())
+
+
+class SequenceParallelScorer:
+    def __init__(self, model: StripedHyena, rank: int, world: int, group=None, comm=None):
+        self.m = model
+        self.rank, self.world = rank, world
+        self.comm = comm if comm is not None else DistComm(group)
+        self._pow_cache = {}
+
+    def _gather0(self, t: torch.Tensor, async_op: bool = False):
+        return self.comm.all_gather(t, async_op=async_op)
+
+    # ------------------------------------------------------------------ shard geometry
+    def shard(self, T: int):
+        Tl = (T + self.world - 1) // self.world
+        t0 = min(T, self.rank * Tl)
+        t1 = min(T, t0 + Tl)
+        return Tl, t0, t1
+
+    def _pole_powers(self, poles: torch.Tensor, Tl: int) -> torch.Tensor:
+        """[R, D, 8] complex128: p^(Tl*k) for k = 0..R-1 (fp64: the carry must stay exact over the whole context)."""
+        key = (poles.data_ptr(), Tl)
+        hit = self._pow_cache.get(key)
+        if hit is None:
+            p = torch.view_as_complex(poles.double().contiguous())
+            logp = torch.log(p)
+            k = torch.arange(self.world, device=poles.device, dtype=torch.float64)
+            hit = torch.exp(logp[None] * (k * Tl)[:, None, None])
+            if len(self._pow_cache) > 64:
+                self._pow_cache.clear()
+            self._pow_cache[key] = hit
+        return hit
+
+    # ------------------------------------------------------------------ blocks
+    def _hyena_block(self, blk, x2d, B, Tloc, Tl):
+        m, ops = self.m, self.m.ops
+        D, H = m.hidden_size, m.num_heads
+        f = blk.filter
+        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
+        z = ops.linear(n1, blk.projections.weight, blk.projections.bias).view(B, Tloc, 3 * D)
+        # (1) halo: every rank publishes its last two rows; rank r reads rank r-1's
+        tail = z[:, -2:, :] if Tloc >= 2 else torch.cat([z.new_zeros(B, 2 - Tloc, 3 * D), z], dim=1)
+        tails, _ = self._gather0(tail)
+        halo = tails[self.rank - 1].contiguous() if self.rank > 0 else None
+        # (2) shard end state from a zero carry-in, (3) exchange
+        st1, e_r = ops.hyena_stage1(z, f._fir_w, f.short_filter_bias, f._poles, H, z_halo=halo)
+        ends, _ = self._gather0(torch.view_as_real(e_r.to(torch.complex64)))
+        # (4) carry entering this shard
+        s0 = None
+        if self.rank > 0:
+            pw = self._pole_powers(f._poles, Tl)                               # [R, D, 8]
+            e = torch.view_as_complex(ends[: self.rank].double().contiguous())  # [r, B, D, 8]
+            idx = torch.arange(self.rank - 1, -1, -1, device=e.device)         # exponent index r-1-q
+            s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
+        # (5)
+        y = ops.hyena_stage2(z, f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1, z_halo=halo, s0=s0)
+        ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
+        m._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
+
+    def _attn_block(self, blk, x2d, B, Tloc, Tl, t0):
+        m, ops = self.m, self.m.ops
+        D, H, hd = m.hidden_size, m.num_heads, m.head_dim
+        mha = blk.inner_mha_cls
+        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
+        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, Tloc, 3, H, hd)
+        cos, sin = m._rotary(t0, Tloc, x2d.device)
+        ops.rope_(qkv, cos, sin)
+        # K,V per batch row, padded to Tl tokens, gathered asynchronously: [R, Tl, 2, H, hd] == tokens 0..R*Tl-1
+        works, bufs = [], []
+        for b in range(B):
+            kv = qkv[b, :, 1:3]
+            if Tloc < Tl:
+                kv = torch.cat([kv, kv.new_zeros(Tl - Tloc, 2, H, hd)], dim=0)
+            g, w = self._gather0(kv, async_op=True)
+            bufs.append(g)
+            works.append(w)
+        a = torch.empty(B, Tloc, H, hd, dtype=qkv.dtype, device=qkv.device)
+        n_keys = t0 + Tloc                                                     # causal: nothing past our last token
+        for b in range(B):
+            works[b].wait()
+            kvg = bufs[b].view(self.world * Tl, 2, H, hd)[:n_keys]
+            a[b:b + 1] = ops.attention(qkv[b:b + 1, :, 0], kvg[None, :, 0], kvg[None, :, 1], t0)
+        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight)
+        m._mlp_residual_(blk, x2d, mha.out_proj.bias)
+
+    # ------------------------------------------------------------------ forward / scoring
+    @torch.no_grad()
+    def forward_local(self, ids_full: torch.Tensor) -> torch.Tensor:
+        """ids_full [B, T] (same on every rank) -> this rank's logits [B, Tloc, V]."""
+        m = self.m
+        if not m._packed:
+            m._pack()
+        B, T = ids_full.shape
+        Tl, t0, t1 = self.shard(T)
+        Tloc = t1 - t0
+        if Tloc <= 0:
+            raise ValueError("sequence shorter than the number of ranks")
+        ops = m.ops
+        h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight)
+        for blk in m.blocks:
+            if isinstance(blk, _AttentionBlock):
+                self._attn_block(blk, h, B, Tloc, Tl, t0)
+            else:
+                self._hyena_block(blk, h, B, Tloc, Tl)
+        if m.norm is not None:
+            h = ops.rmsnorm(h, None, m.norm.scale, m.eps)
+        return ops.linear(h, m.unembed.weight, None).view(B, Tloc, m.vocab_size)
+
+    @torch.no_grad()
+    def score_logprobs(self, ids_full: torch.Tensor) -> torch.Tensor:
+        """Log-prob of each next token for this rank's positions: [B, n_local] f32, where global position t
+        (t0 <= t < min(t1, T-1)) scores token t+1 -- the rank-local part of evo.scoring.logits_to_logprobs."""
+        B, T = ids_full.shape
+        _, t0, t1 = self.shard(T)
+        logits = self.forward_local(ids_full)
+        n = min(t1, T - 1) - t0
+        if n <= 0:
+            return logits.new_zeros(B, 0, dtype=torch.float32)
+        tgt = ids_full[:, t0 + 1: t0 + 1 + n].to(logits.device)
+        lg = logits[:, :n].reshape(B * n, -1).contiguous()
+        lp, _ = self.m.ops.logprob_entropy(lg, tgt.reshape(-1))
+        return lp.view(B, n)
+
+    def gather_logprobs(self, local: torch.Tensor, T: int) -> torch.Tensor:
+        """All ranks -> full [B, T-1] log-prob matrix (for score_sequences-style reductions)."""
+        Tl, _, _ = self.shard(T)
+        pad = torch.zeros(local.shape[0], Tl, dtype=local.dtype, device=local.device)
+        pad[:, : local.shape[1]] = local
+        g, _ = self._gather0(pad)
+        return g.permute(1, 0, 2).reshape(local.shape[0], -1)[:, : T - 1]

@@ -72,6 +72,10 @@ int evo_hyena_seg_state(const void* z, const void* z_halo, const void* fir_w, co
                         int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
 int evo_hyena_carry_scan(float* agg, const float* poles, const float* s0, float* s_final,
                          int64_t B, int64_t T, int64_t D, int64_t seg_len, void* stream);
+/* sequence-parallel fix-up (new; the reference has no multi-GPU path): `agg` already scanned with a zero
+ * carry-in gets p^(k*seg_len) * s0 added to segment k once the state s0 entering this shard is known. */
+int evo_hyena_carry_add(float* agg, const float* poles, const float* s0,
+                        int64_t B, int64_t T, int64_t D, int64_t seg_len, void* stream);
 int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
                     const float* poles, const float* residues, const void* dskip,
                     const float* agg, void* y,

@@ -67,3 +67,11 @@ class OracleOps:
     def logprob_entropy(self, logits, target, want_logprob=True, want_entropy=False):
         lp, en = R.op_logprob_entropy(logits, target)
         return (lp.float() if want_logprob and lp is not None else None), (en.float() if want_entropy else None)
+
+    # stage-wise form used by the sequence-parallel engine
+    def hyena_stage1(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
+        return None, self.hyena_end_state(z, fir_w, fir_b, poles, n_heads, z_halo)
+
+    def hyena_stage2(self, z, fir_w, fir_b, poles, residues, dskip, n_heads, stage1, z_halo=None, s0=None):
+        y, _ = R.op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo, s0)
+        return self._o(y)

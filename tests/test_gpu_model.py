@@ -87,16 +87,18 @@ def test_cached_decode_consistent_with_parallel_and_oracle():
     ref = R.RefStripedHyena(cfg, sd, "fp64")(ids)[0]
     c = m.initialize_inference_params()
     c["mha"].max_batch_size = c["hyena"].max_batch_size = 2
+    floor = rel_l2(R.RefStripedHyena(cfg, sd, "bf16")(ids)[0], ref)
+    tol = max(1.5 * floor, 4e-3)
     l0, c = m(ids[:, :64].to(DEV), c)
-    assert rel_l2(l0, ref[:, :64]) < 6e-3
+    assert rel_l2(l0, ref[:, :64]) < tol
     steps = []
     for t in range(64, 91):
         c["mha"].seqlen_offset = c["hyena"].seqlen_offset = t
         lt, c = m(ids[:, t:t + 1].to(DEV), c)
         steps.append(lt[:, 0].float().cpu())
     steps = torch.stack(steps, 1)
-    assert rel_l2(steps, ref[:, 64:]) < 6e-3
-    assert rel_l2(steps, full[:, 64:]) < 8e-3
+    assert rel_l2(steps, ref[:, 64:]) < tol
+    assert rel_l2(steps, full[:, 64:]) < 2 * tol
     assert c["hyena"].state_dict[0].dtype == torch.complex64 and c["hyena"].fir_state_dict[0].shape == (2, 768, 2)
     assert c["mha"].key_value_memory_dict[2].shape[2:] == (2, 2, 128)
 
@@ -133,3 +135,74 @@ def test_generate_greedy_on_gpu():
     assert len(a) == 2 and all(len(s) == 12 for s in a)
     np.testing.assert_allclose(sa, sb, rtol=2e-2, atol=2e-2)      # full prefill vs forced recurrence
     np.testing.assert_allclose(sa, sc, rtol=2e-2, atol=2e-2)      # cached vs uncached
+
+
+class _ThreadComm:
+    """R 'virtual ranks' as threads of one process sharing the one GPU of the box: all_gather = slot write +
+    barrier.  Exercises the sequence-parallel host code on the HIP kernels without RCCL (the box has 1 GPU)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.local = threading.local()
+
+    class _W:
+        def wait(self):
+            return True
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def all_gather(self, t, async_op=False):
+        torch.cuda.synchronize()
+        self.slots[self.local.rank] = t.contiguous().clone()
+        self.bar.wait()
+        out = torch.stack(list(self.slots), 0)
+        torch.cuda.synchronize()
+        self.bar.wait()
+        return out, _ThreadComm._W()
+
+
+@pytest.mark.parametrize("world,L", [(2, 700), (4, 1001)])
+def test_sequence_parallel_virtual_ranks_on_hip(world, L):
+    import threading
+    from evo_amd.sp import SequenceParallelScorer
+    cfgd = dict(SMALL, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+    cfg, sd, m = build(cfgd)
+    m._pack()
+    ids = acgt(2, L).to(DEV)
+    T = ids.shape[1]
+    full = m(ids)[0].float().cpu()
+    ref = R.RefStripedHyena(cfg, sd, "fp64")(ids.cpu())[0]
+    comm = _ThreadComm(world)
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm.bind(r)
+            sp = SequenceParallelScorer(m, r, world, comm=comm)
+            with torch.inference_mode():
+                lg = sp.forward_local(ids)
+                lp = sp.score_logprobs(ids)
+            outs[r] = (sp.shard(T), lg.float().cpu(), lp.float().cpu())
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            comm.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+    sharded = torch.cat([o[1] for o in outs], 1)
+    assert sharded.shape == full.shape
+    floor = rel_l2(R.RefStripedHyena(cfg, sd, "bf16")(ids.cpu())[0], ref)
+    tol = max(1.5 * floor, 4e-3)
+    assert rel_l2(sharded, ref) < tol
+    assert rel_l2(sharded, full) < 2 * tol
+    lp = torch.cat([o[2] for o in outs], 1)
+    from evo_amd.scoring import logits_to_logprobs
+    want = logits_to_logprobs(ref, ids.cpu(), trim_bos=True)
+    assert lp.shape == want.shape and (lp.double() - want.double()).abs().mean() < 2e-2
