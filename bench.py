@@ -87,11 +87,13 @@ def flops_per_token(T):
 
 def cpu_baseline(nt=512, layers=(0, 1, 2, 3)):
     """The oracle (a 'port' of the reference forward) on the host cores: a 4-block slice (3 Hyena + 1 attention)
-    at full width on one 512-nt sequence, scaled x8 to the 32-block depth.  fp32 mode: torch's CPU bf16 GEMM
-    ran at ~10 GFLOP/s on the GPU box's EPYC host (85 s for this slice), far outside the 10-30 s budget, so the
-    baseline uses the same bf16-rounded weights up-cast to fp32 (MKL sgemm) -- this FAVOURS the CPU."""
+    at full width on one 512-nt sequence, scaled x8 to the 32-block depth.  fp32 mode (the same bf16-rounded
+    weights up-cast to fp32, MKL sgemm): torch's CPU bf16 path was slower still on the GPU box's EPYC host, so
+    this choice FAVOURS the CPU."""
     from oracle import stripedhyena_ref as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 32 threads: with all 256 hardware threads of the GPU box's host the same slice took 65 s (oversubscribed
+    # small ops) against ~2 s on 8 threads elsewhere; `cores` reports what was actually used
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cfg = R.RefConfig(num_layers=4, attn_layer_idxs=(2,))
     sd = R.make_synthetic_state_dict(cfg, 0)
     m = R.RefStripedHyena(cfg, sd, "fp32")

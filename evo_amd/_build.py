@@ -13,7 +13,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "_lib"
-LIBNAME = "libevo_mi355x.so"
+# A/B builds: EVO_AMD_LIBNAME picks another file name in _lib/, EVO_AMD_HIPCC_FLAGS appends compiler flags
+LIBNAME = os.environ.get("EVO_AMD_LIBNAME", "libevo_mi355x.so")
 ARCH = "gfx950"
 
 # every symbol include/evo_mi355x.h declares
@@ -56,7 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     tmp = out.with_suffix(".so.tmp%d" % os.getpid())
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-o", str(tmp)] + [str(s) for s in sources()]
+           "-fno-gpu-rdc", "-o", str(tmp)] + os.environ.get("EVO_AMD_HIPCC_FLAGS", "").split() \
+        + [str(s) for s in sources()]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)

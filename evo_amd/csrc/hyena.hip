@@ -4,45 +4,58 @@
 // Long convolution: the filter is h_k = Re sum_{s<8} R_s p_s^k, so y = h (*) x1v is evaluated exactly
 // through the 8 complex modes   S_t = p S_{t-1} + x1v_t ,  y_t = Re sum_s R_s S_t   (fp32).  Time is cut
 // into segments of C steps; one wave owns (batch b, head h, segment k) and its 64 lanes own the head's
-// 128 channels two at a time, so every global access of a wave is one contiguous 256-byte row piece:
+// 128 channels two at a time:
 //   launch 1  seg_state : segment end state from a zero start (reads the x1,v thirds of z)
 //   launch 2  carry_scan: exclusive scan over segments with p^C (fp64 powers) -> state entering each
 //   launch 3  apply     : the full recurrence from the entering state + FIR + gates, writes y
 // Algorithmic HBM bytes per token per layer: 3D*2 in + D*2 out = 32,768 B (D = 4096); this 3-launch
 // form moves 49,152 B (the x1,v thirds are read twice) plus 128*D*8/C bytes of segment states.
+//
+// Streaming: a head's slice of one z row is ONE contiguous piece (768 B = x2|x1|v, or its 512-B x1|v tail).
+// Each wave keeps a private ring of NSLOT chunks (4 rows each) in LDS, filled by asynchronous
+// global->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip) five chunks
+// ahead of the math and retired with a COUNTED s_waitcnt vmcnt(N): ~15 KiB per wave / ~120 KiB per CU in
+// flight.  (The first version prefetched through registers, 3 KiB per wave, and sat at 3.6-3.8 TB/s,
+// bound by latency x bytes-in-flight, not by HBM or VALU.)  No barriers: waves never share LDS.
 // Entry points and reference citations: include/evo_mi355x.h.
 #include "common.h"
 #include "../../include/evo_mi355x.h"
 
 #define NS 8            // state_size   [REF evo/configs/evo-1-8k-base_inference.yml:14]
 #define HD 128          // channels per head (hidden_size / num_attention_heads)  [REF yml:2,9]
-#define UNR 4           // time steps per software-pipelined group
+#define CH 4            // rows (time steps) per DMA chunk
+#define NSLOT 6         // ring depth in chunks: NSLOT-1 chunks are in flight while one is consumed
 
-struct RowPtr {         // the three 256-byte pieces (x2 | x1 | v) of one head in one z row, as dwords
-    const uint32_t* p;
-};
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
-// per-lane constants of one head-slice: 2 channels (lo, hi) of each of the 3 groups
+// All per-lane math runs on f32x2 = (channel 2j, channel 2j+1): one v_pk_fma_f32 per pair of FMAs.  The pairs
+// are built by hand (hipcc's SLP pass found the same packing but paid ~45 v_mov per step to assemble them).
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t bf2_unpack(uint32_t w) { f32x2_t r = {bf_lo(w), bf_hi(w)}; return r; }
+
+// per-lane constants of one head-slice: the (lo, hi) channel pair of each of the 3 groups
 struct FirCoef {
-    float w[3][2][3];   // [group][lo/hi][tap]
-    float b[3][2];
+    f32x2_t w[3][3];   // [group][tap]
+    f32x2_t b[3];
 };
 
 __device__ __forceinline__ void load_fir(FirCoef& fc, const uint16_t* __restrict__ fir_w,
                                          const uint16_t* __restrict__ fir_b, int c_base, int lane, int g_first) {
 #pragma unroll
     for (int g = g_first; g < 3; ++g) {
+        const int c = c_base + g * HD + 2 * lane;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int c = c_base + g * HD + 2 * lane + e;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) fc.w[g][e][k] = bf_to_f(fir_w[c * 3 + k]);
-            fc.b[g][e] = bf_to_f(fir_b[c]);
+        for (int k = 0; k < 3; ++k) {
+            f32x2_t v = {bf_to_f(fir_w[c * 3 + k]), bf_to_f(fir_w[(c + 1) * 3 + k])};
+            fc.w[g][k] = v;
         }
+        f32x2_t bb = {bf_to_f(fir_b[c]), bf_to_f(fir_b[c + 1])};
+        fc.b[g] = bb;
     }
 }
 
-// raw z dword of group g at (relative) time t for this lane; t < 0 reads the halo (or zero)
+// raw z dword at (relative) time t for this lane; t < 0 reads the halo (or zero)
 __device__ __forceinline__ uint32_t load_hist(const uint32_t* __restrict__ zrow0, const uint32_t* __restrict__ halo,
                                               int64_t t_abs, int64_t rowdw, int col) {
     if (t_abs >= 0) return zrow0[t_abs * rowdw + col];
@@ -50,97 +63,134 @@ __device__ __forceinline__ uint32_t load_hist(const uint32_t* __restrict__ zrow0
     return 0u;
 }
 
+// One DMA chunk = CH rows x ROWB bytes, laid out linearly in LDS; instruction i moves LDS bytes
+// [i*1024, (i+1)*1024) of the chunk, lane l the 16 bytes at i*1024 + 16*l  ->  (row, column) of the source.
+template <int ROWB>
+struct ChunkMap {
+    static constexpr int CHUNKB = CH * ROWB;
+    static constexpr int NDMA = CHUNKB / 1024;
+    int row[NDMA];
+    int colb[NDMA];
+    __device__ __forceinline__ void init(int lane, int head_col_bytes) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int pos = i * 1024 + 16 * lane;
+            row[i] = pos / ROWB;
+            colb[i] = head_col_bytes + pos % ROWB;
+        }
+    }
+    // rows past the end of the sequence are clamped to the last row (loaded, never used)
+    __device__ __forceinline__ void issue(const unsigned char* zb_bytes, int64_t t_first, int64_t t_last_valid,
+                                          int64_t rowbytes, unsigned char* lds_chunk) const {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            int64_t t = t_first + row[i];
+            t = t < t_last_valid ? t : t_last_valid;
+            const unsigned char* src = zb_bytes + t * rowbytes + colb[i];
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_chunk + i * 1024), 16, 0, 0);
+        }
+    }
+};
+
+// Counted retire of the ring.  The VM counter retires in issue order and counts loads AND stores (gfx9 family;
+// LLVM's SIInsertWaitcnts models it the same way), so "chunk c has landed" == "at most as many VMEM ops
+// outstanding as were issued after chunk c's DMA".  In the steady state that is, per ring stage, NDMA DMA
+// instructions plus the y stores of one chunk (apply: 4; seg_state: 0), times NSLOT-1 stages.  Counting the
+// stores matters: waiting them out too (vmcnt(15)) stalled every chunk on the ~2 us store latency.
+#define HY_WAIT_STATE() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")   /* 2 DMA x 5 stages            */
+#define HY_WAIT_APPLY() asm volatile("s_waitcnt vmcnt(35)" ::: "memory")   /* (3 DMA + 4 stores) x 5 stages */
+static_assert(NSLOT == 6 && CH == 4, "HY_WAIT_* immediates assume 5 stages in flight and 4 stores per chunk");
+
 // ------------------------------------------------------------------------------------------------ launch 1
 __global__ __launch_bounds__(256, 2) void hyena_seg_state_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
     const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, float* __restrict__ agg, int B, int64_t T,
     int D, int H, int C, int n_seg) {
+    constexpr int ROWB = 2 * HD * 2;                                   // x1|v = 512 B
+    typedef ChunkMap<ROWB> Map;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NSLOT * Map::CHUNKB];
     const int lane = threadIdx.x & 63;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;                 // wave-uniform (SGPR)
     const int64_t total = (int64_t)B * n_seg * H;
     if (gw >= total) return;
     const int h = (int)(gw % H);
     const int seg = (int)((gw / H) % n_seg);
     const int b = (int)(gw / ((int64_t)H * n_seg));
     const int64_t rowdw = 3 * (int64_t)D / 2;
+    const int64_t rowbytes = rowdw * 4;
     const int64_t t0 = (int64_t)seg * C;
     const int64_t t1 = (t0 + C < T) ? t0 + C : T;
+    unsigned char* ring = smem + wave * (NSLOT * Map::CHUNKB);
+
+    const uint32_t* zb = z + (int64_t)b * T * rowdw;
+    const unsigned char* zbb = (const unsigned char*)zb;
+    Map map;
+    map.init(lane, (h * 3 * HD + HD) * 2);
+    const int nch = (int)((t1 - t0 + CH - 1) / CH);
+#pragma unroll
+    for (int c = 0; c < NSLOT - 1; ++c)
+        if (c < nch) map.issue(zbb, t0 + CH * c, T - 1, rowbytes, ring + c * Map::CHUNKB);
 
     FirCoef fc;
     load_fir(fc, fir_w, fir_b, h * 3 * HD, lane, 1);
-
-    float pr[2][NS], pi[2][NS], sr[2][NS], si[2][NS];
+    f32x2_t pr[NS], pi[NS], sr[NS], si[NS];
     {
         const float* pp = poles + ((int64_t)(h * HD + 2 * lane)) * NS * 2;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                pr[e][s] = pp[(e * NS + s) * 2];
-                pi[e][s] = pp[(e * NS + s) * 2 + 1];
-                sr[e][s] = 0.f;
-                si[e][s] = 0.f;
-            }
+        for (int s = 0; s < NS; ++s) {
+            f32x2_t a = {pp[s * 2], pp[(NS + s) * 2]}, c = {pp[s * 2 + 1], pp[(NS + s) * 2 + 1]}, zz = {0.f, 0.f};
+            pr[s] = a; pi[s] = c; sr[s] = zz; si[s] = zz;
+        }
     }
-
-    const uint32_t* zb = z + (int64_t)b * T * rowdw;
     const uint32_t* hb = z_halo ? z_halo + (int64_t)b * 2 * rowdw : nullptr;
     const int col1 = (h * 3 * HD + HD) / 2 + lane;       // x1 third
     const int col2 = (h * 3 * HD + 2 * HD) / 2 + lane;   // v third
-
-    // history z[t-2], z[t-1] (unpacked) for groups x1 (index 0) and v (index 1)
-    float m2[2][2], m1[2][2];
-    {
-        uint32_t a = load_hist(zb, hb, t0 - 2, rowdw, col1), c = load_hist(zb, hb, t0 - 2, rowdw, col2);
-        m2[0][0] = bf_lo(a); m2[0][1] = bf_hi(a); m2[1][0] = bf_lo(c); m2[1][1] = bf_hi(c);
-        a = load_hist(zb, hb, t0 - 1, rowdw, col1); c = load_hist(zb, hb, t0 - 1, rowdw, col2);
-        m1[0][0] = bf_lo(a); m1[0][1] = bf_hi(a); m1[1][0] = bf_lo(c); m1[1][1] = bf_hi(c);
-    }
+    // history z[t-2], z[t-1] for groups x1 (index 0) and v (index 1)
+    f32x2_t m2[2], m1[2];
+    m2[0] = bf2_unpack(load_hist(zb, hb, t0 - 2, rowdw, col1));
+    m2[1] = bf2_unpack(load_hist(zb, hb, t0 - 2, rowdw, col2));
+    m1[0] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col1));
+    m1[1] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col2));
 
     auto step = [&](uint32_t zx1, uint32_t zv) {
-        float c0[2][2];
-        c0[0][0] = bf_lo(zx1); c0[0][1] = bf_hi(zx1); c0[1][0] = bf_lo(zv); c0[1][1] = bf_hi(zv);
+        const f32x2_t c0 = bf2_unpack(zx1), c1 = bf2_unpack(zv);
+        const f32x2_t x1c = pk_fma(fc.w[1][2], c0, pk_fma(fc.w[1][1], m1[0], pk_fma(fc.w[1][0], m2[0], fc.b[1])));
+        const f32x2_t vc = pk_fma(fc.w[2][2], c1, pk_fma(fc.w[2][1], m1[1], pk_fma(fc.w[2][0], m2[1], fc.b[2])));
+        const f32x2_t x = x1c * vc;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float x1c = fmaf(fc.w[1][e][2], c0[0][e], fmaf(fc.w[1][e][1], m1[0][e], fmaf(fc.w[1][e][0], m2[0][e], fc.b[1][e])));
-            float vc = fmaf(fc.w[2][e][2], c0[1][e], fmaf(fc.w[2][e][1], m1[1][e], fmaf(fc.w[2][e][0], m2[1][e], fc.b[2][e])));
-            float x = x1c * vc;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float nr = fmaf(pr[e][s], sr[e][s], fmaf(-pi[e][s], si[e][s], x));
-                float ni = fmaf(pr[e][s], si[e][s], pi[e][s] * sr[e][s]);
-                sr[e][s] = nr;
-                si[e][s] = ni;
-            }
+        for (int s = 0; s < NS; ++s) {
+            const f32x2_t nr = pk_fma(pr[s], sr[s], pk_fma(-pi[s], si[s], x));
+            const f32x2_t ni = pk_fma(pr[s], si[s], pi[s] * sr[s]);
+            sr[s] = nr;
+            si[s] = ni;
         }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { m2[g][e] = m1[g][e]; m1[g][e] = c0[g][e]; }
+        m2[0] = m1[0]; m1[0] = c0; m2[1] = m1[1]; m1[1] = c1;
     };
 
-    // ring prefetch: the raw rows of steps t..t+UNR-1 are in flight while step t-1.. computes
-    const uint32_t* zp = zb + t0 * rowdw;
-    const int n_full = (int)((t1 - t0) / UNR);
-    uint32_t ring[UNR][2];
-    if (n_full > 0) {
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) { ring[k][0] = zp[k * rowdw + col1]; ring[k][1] = zp[k * rowdw + col2]; }
-    }
-    for (int g = 0; g < n_full; ++g) {
-        const uint32_t* zn = zp + UNR * rowdw;
-        const bool more = g + 1 < n_full;
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const uint32_t a = ring[k][0], c = ring[k][1];
-            if (more) { ring[k][0] = zn[k * rowdw + col1]; ring[k][1] = zn[k * rowdw + col2]; }
-            step(a, c);
+    // prologue chunks + parameter loads have all landed past this point: the counted waits below only ever
+    // reason about VMEM ops issued inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int slot = 0, fill = NSLOT - 1;
+    for (int c = 0; c < nch; ++c) {
+        if (c + NSLOT - 1 < nch) {
+            map.issue(zbb, t0 + CH * (int64_t)(c + NSLOT - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
+            HY_WAIT_STATE();                               // chunk c has landed; 5 younger chunks stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        zp = zn;
-    }
-    for (int64_t t = t0 + (int64_t)n_full * UNR; t < t1; ++t) {
-        step(zp[col1], zp[col2]);
-        zp += rowdw;
+        const unsigned char* sp = ring + slot * Map::CHUNKB + 4 * lane;
+        const int64_t tb = t0 + CH * (int64_t)c;
+        if (tb + CH <= t1) {                               // full chunk: one basic block, 4 steps scheduled together
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256));
+        } else {                                           // ragged end of the sequence
+            for (int k = 0; k < CH && tb + k < t1; ++k)
+                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256));
+        }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == NSLOT ? 0 : fill + 1;
     }
 
     float4* out = (float4*)(agg + ((((int64_t)b * n_seg + seg) * D + h * HD + 2 * lane) * NS) * 2);
@@ -148,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void hyena_seg_state_kernel(
     for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int s = 0; s < NS; s += 2)
-            out[(e * NS + s) / 2] = make_float4(sr[e][s], si[e][s], sr[e][s + 1], si[e][s + 1]);
+            out[(e * NS + s) / 2] = make_float4(sr[s][e], si[s][e], sr[s + 1][e], si[s + 1][e]);
 }
 
 // ------------------------------------------------------------------------------------------------ launch 2
@@ -247,121 +297,121 @@ __global__ __launch_bounds__(256, 2) void hyena_apply_kernel(
     const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, const float* __restrict__ residues,
     const uint16_t* __restrict__ dskip, const float* __restrict__ agg, uint32_t* __restrict__ y, int B, int64_t T, int D,
     int H, int C, int n_seg) {
+    constexpr int ROWB = 3 * HD * 2;                                   // x2|x1|v = 768 B
+    typedef ChunkMap<ROWB> Map;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NSLOT * Map::CHUNKB];
     const int lane = threadIdx.x & 63;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;                 // wave-uniform (SGPR)
     const int64_t total = (int64_t)B * n_seg * H;
     if (gw >= total) return;
     const int h = (int)(gw % H);
     const int seg = (int)((gw / H) % n_seg);
     const int b = (int)(gw / ((int64_t)H * n_seg));
     const int64_t rowdw = 3 * (int64_t)D / 2;
+    const int64_t rowbytes = rowdw * 4;
     const int64_t t0 = (int64_t)seg * C;
     const int64_t t1 = (t0 + C < T) ? t0 + C : T;
+    unsigned char* ring = smem + wave * (NSLOT * Map::CHUNKB);
+
+    const uint32_t* zb = z + (int64_t)b * T * rowdw;
+    const unsigned char* zbb = (const unsigned char*)zb;
+    Map map;
+    map.init(lane, (h * 3 * HD) * 2);
+    const int nch = (int)((t1 - t0 + CH - 1) / CH);
+#pragma unroll
+    for (int c = 0; c < NSLOT - 1; ++c)
+        if (c < nch) map.issue(zbb, t0 + CH * c, T - 1, rowbytes, ring + c * Map::CHUNKB);
 
     FirCoef fc;
     load_fir(fc, fir_w, fir_b, h * 3 * HD, lane, 0);
-
-    float pr[2][NS], pi[2][NS], rr[2][NS], ri[2][NS], sr[2][NS], si[2][NS], dk[2];
+    f32x2_t pr[NS], pi[NS], rr[NS], ri[NS], sr[NS], si[NS], dk;
     {
         const int64_t d0 = h * HD + 2 * lane;
         const float* pp = poles + d0 * NS * 2;
         const float* rp = residues + d0 * NS * 2;
         const float4* sp = (const float4*)(agg + ((((int64_t)b * n_seg + seg) * D + d0) * NS) * 2);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                pr[e][s] = pp[(e * NS + s) * 2];
-                pi[e][s] = pp[(e * NS + s) * 2 + 1];
-                rr[e][s] = rp[(e * NS + s) * 2];
-                ri[e][s] = rp[(e * NS + s) * 2 + 1];
-            }
-#pragma unroll
-            for (int s = 0; s < NS; s += 2) {
-                float4 v = sp[(e * NS + s) / 2];
-                sr[e][s] = v.x; si[e][s] = v.y; sr[e][s + 1] = v.z; si[e][s + 1] = v.w;
-            }
-            dk[e] = bf_to_f(dskip[d0 + e]);
+        for (int s = 0; s < NS; ++s) {
+            f32x2_t a = {pp[s * 2], pp[(NS + s) * 2]}, c = {pp[s * 2 + 1], pp[(NS + s) * 2 + 1]};
+            f32x2_t e = {rp[s * 2], rp[(NS + s) * 2]}, f = {rp[s * 2 + 1], rp[(NS + s) * 2 + 1]};
+            pr[s] = a; pi[s] = c; rr[s] = e; ri[s] = f;
         }
+#pragma unroll
+        for (int s = 0; s < NS; s += 2) {
+            const float4 lo = sp[s / 2], hi = sp[(NS + s) / 2];
+            f32x2_t a = {lo.x, hi.x}, c = {lo.y, hi.y}, e = {lo.z, hi.z}, f = {lo.w, hi.w};
+            sr[s] = a; si[s] = c; sr[s + 1] = e; si[s + 1] = f;
+        }
+        f32x2_t d2 = {bf_to_f(dskip[d0]), bf_to_f(dskip[d0 + 1])};
+        dk = d2;
     }
-
-    const uint32_t* zb = z + (int64_t)b * T * rowdw;
     const uint32_t* hb = z_halo ? z_halo + (int64_t)b * 2 * rowdw : nullptr;
     const int col0 = (h * 3 * HD) / 2 + lane;     // x2 third; x1 = +HD/2 dwords, v = +HD dwords
-
-    float m2[3][2], m1[3][2];
+    f32x2_t m2[3], m1[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        uint32_t a = load_hist(zb, hb, t0 - 2, rowdw, col0 + g * (HD / 2));
-        m2[g][0] = bf_lo(a); m2[g][1] = bf_hi(a);
-        a = load_hist(zb, hb, t0 - 1, rowdw, col0 + g * (HD / 2));
-        m1[g][0] = bf_lo(a); m1[g][1] = bf_hi(a);
+        m2[g] = bf2_unpack(load_hist(zb, hb, t0 - 2, rowdw, col0 + g * (HD / 2)));
+        m1[g] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col0 + g * (HD / 2)));
     }
 
     auto step = [&](const uint32_t (&zr)[3]) -> uint32_t {
-        float c0[3][2], out[2];
+        f32x2_t c0[3], f[3];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) { c0[g][0] = bf_lo(zr[g]); c0[g][1] = bf_hi(zr[g]); }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float f[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                f[g] = fmaf(fc.w[g][e][2], c0[g][e], fmaf(fc.w[g][e][1], m1[g][e], fmaf(fc.w[g][e][0], m2[g][e], fc.b[g][e])));
-            const float x = f[1] * f[2];           // x1 * v
-            float acc = 0.f;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float nr = fmaf(pr[e][s], sr[e][s], fmaf(-pi[e][s], si[e][s], x));
-                float ni = fmaf(pr[e][s], si[e][s], pi[e][s] * sr[e][s]);
-                sr[e][s] = nr;
-                si[e][s] = ni;
-                acc = fmaf(rr[e][s], nr, fmaf(-ri[e][s], ni, acc));
-            }
-            out[e] = fmaf(x, dk[e], acc) * f[0];   // (y + x1v * D) * x2
+        for (int g = 0; g < 3; ++g) {
+            c0[g] = bf2_unpack(zr[g]);
+            f[g] = pk_fma(fc.w[g][2], c0[g], pk_fma(fc.w[g][1], m1[g], pk_fma(fc.w[g][0], m2[g], fc.b[g])));
         }
+        const f32x2_t x = f[1] * f[2];             // x1 * v
+        f32x2_t acc = {0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int s = 0; s < NS; ++s) {
+            const f32x2_t nr = pk_fma(pr[s], sr[s], pk_fma(-pi[s], si[s], x));
+            const f32x2_t ni = pk_fma(pr[s], si[s], pi[s] * sr[s]);
+            sr[s] = nr;
+            si[s] = ni;
+            acc = pk_fma(rr[s], nr, pk_fma(-ri[s], ni, acc));
+        }
+        const f32x2_t out = pk_fma(x, dk, acc) * f[0];   // (y + x1v * D) * x2
 #pragma unroll
-            for (int e = 0; e < 2; ++e) { m2[g][e] = m1[g][e]; m1[g][e] = c0[g][e]; }
+        for (int g = 0; g < 3; ++g) { m2[g] = m1[g]; m1[g] = c0[g]; }
         return pack_bf2(out[0], out[1]);
     };
 
-    const uint32_t* zp = zb + t0 * rowdw + col0;
     uint32_t* yp = y + ((int64_t)b * T + t0) * (D / 2) + h * (HD / 2) + lane;
     const int ydw = D / 2;
-    const int n_full = (int)((t1 - t0) / UNR);
-    uint32_t ring[UNR][3];
-    if (n_full > 0) {
-#pragma unroll
-        for (int k = 0; k < UNR; ++k)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) ring[k][g] = zp[k * rowdw + g * (HD / 2)];
-    }
-    for (int gi = 0; gi < n_full; ++gi) {
-        const uint32_t* zn = zp + UNR * rowdw;
-        const bool more = gi + 1 < n_full;
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            uint32_t zr[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) zr[g] = ring[k][g];
-            if (more) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) ring[k][g] = zn[k * rowdw + g * (HD / 2)];
-            }
-            yp[(int64_t)k * ydw] = step(zr);
+    // prologue chunks + parameter loads have all landed past this point: the counted waits below only ever
+    // reason about VMEM ops issued inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int slot = 0, fill = NSLOT - 1;
+    for (int c = 0; c < nch; ++c) {
+        if (c + NSLOT - 1 < nch) {
+            map.issue(zbb, t0 + CH * (int64_t)(c + NSLOT - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
+            HY_WAIT_APPLY();                               // chunk c has landed; 5 younger chunks stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        zp = zn;
-        yp += (int64_t)UNR * ydw;
-    }
-    for (int64_t t = t0 + (int64_t)n_full * UNR; t < t1; ++t) {
-        uint32_t zr[3];
+        const unsigned char* sp = ring + slot * Map::CHUNKB + 4 * lane;
+        const int64_t tb = t0 + CH * (int64_t)c;
+        if (tb + CH <= t1) {                               // full chunk: one basic block, 4 steps scheduled together
 #pragma unroll
-        for (int g = 0; g < 3; ++g) zr[g] = zp[g * (HD / 2)];
-        *yp = step(zr);
-        zp += rowdw;
-        yp += ydw;
+            for (int k = 0; k < CH; ++k) {
+                uint32_t zr[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) zr[g] = *(const uint32_t*)(sp + k * ROWB + g * 256);
+                yp[(int64_t)k * ydw] = step(zr);
+            }
+        } else {                                           // ragged end of the sequence
+            for (int k = 0; k < CH && tb + k < t1; ++k) {
+                uint32_t zr[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) zr[g] = *(const uint32_t*)(sp + k * ROWB + g * 256);
+                yp[(int64_t)k * ydw] = step(zr);
+            }
+        }
+        yp += (int64_t)CH * ydw;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        fill = fill + 1 == NSLOT ? 0 : fill + 1;
     }
 }
 
@@ -421,7 +471,7 @@ __global__ __launch_bounds__(256) void hyena_step_kernel(
 static int hyena_check(int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len) {
     if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0) return -1;
     if (D != n_heads * HD) return -1;                 // one wave per 128-channel head
-    if (seg_len <= 0 || seg_len % UNR != 0) return -1;
+    if (seg_len <= 0 || seg_len % CH != 0) return -1;
     return 0;
 }
 

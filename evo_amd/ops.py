@@ -82,7 +82,7 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def pick_segment_length(B: int, T: int, H: int, target_waves: int = 8192) -> int:
+def pick_segment_length(B: int, T: int, H: int, target_waves: int = 4096) -> int:
     """Time-segment length C of the Hyena kernels: enough (b, head, segment) waves to fill 256 CUs,
     power of two in [64, 1024]."""
     c = 1024

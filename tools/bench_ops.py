@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Per-kernel HIP-event timings of the hand-written kernels at the bench shapes (A/B helper).
+    [EVO_AMD_LIBNAME=libevo_variant.so EVO_AMD_NO_REBUILD=1] python tools/bench_ops.py [--seg-len C] [--only hyena|attn]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--seg-len", type=int, default=0)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--attn-T", type=int, default=16385)
+    args = ap.parse_args()
+    from evo_amd.ops import KernelTimer, default_ops
+    ops = default_ops()
+    dev = "cuda:0"
+    D, H, I = 4096, 32, 10928
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s, std=1.0: (torch.randn(*s, generator=g, device=dev) * std)   # noqa: E731
+    fir_w = rn(3 * D, 3, std=0.3).bfloat16()
+    fir_b = rn(3 * D, std=0.1).bfloat16()
+    u = torch.rand(D, 8, generator=g, device=dev)
+    mag = 1.0 - 10.0 ** (-5.0 + 4.0 * u)
+    ang = (torch.rand(D, 8, generator=g, device=dev) * 2 - 1) * math.pi
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous()
+    res = rn(D, 8, 2, std=0.25).float().contiguous()
+    dskip = rn(D, std=0.5).bfloat16()
+    tag = os.environ.get("EVO_AMD_LIBNAME", "default")
+    if args.only in ("", "hyena"):
+        for (B, T) in ((8, 8193), (1, 131073)):
+            z = rn(B, T, 3 * D).bfloat16()
+            for _ in range(2):
+                ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, seg_len=args.seg_len or None)
+            ops.timer = KernelTimer()
+            for _ in range(args.reps):
+                ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, seg_len=args.seg_len or None)
+            torch.cuda.synchronize()
+            s = ops.timer.summary()
+            ops.timer = None
+            alg = B * T * D * 8
+            tot = sum(v[1] for v in s.values())
+            print(f"[{tag}] hyena B={B} T={T} seg={args.seg_len or 'auto'}: " +
+                  " ".join(f"{k.replace('hyena_', '')}={v[1]:.3f}ms" for k, v in s.items()) +
+                  f" | apply {alg / s['hyena_apply'][1] / 1e6:.0f} GB/s, operator {alg / tot / 1e6:.0f} GB/s")
+            del z
+    if args.only in ("", "attn"):
+        for T in (8193, args.attn_T):
+            Bq = 8 if T == 8193 else 1
+            qkv = rn(Bq, T, 3, H, 128).bfloat16()
+            for _ in range(1):
+                ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+            ops.timer = KernelTimer()
+            for _ in range(max(2, args.reps // 3)):
+                ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+            torch.cuda.synchronize()
+            ms = ops.timer.summary()["attn_fwd"][1]
+            ops.timer = None
+            fl = Bq * 4 * D * T * T / 2
+            print(f"[{tag}] attn B={Bq} T={T}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
+            del qkv
+
+
+if __name__ == "__main__":
+    main()
