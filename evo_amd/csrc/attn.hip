@@ -38,9 +38,9 @@ struct AttnArgs {
 };
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KB * DH * 2];
-    unsigned char* Ks = smem;
-    unsigned char* Vt = smem + KB * DH * 2;
+    // two stages of {Ks 16 KiB, Vt 16 KiB}: tile t+1 is written while tile t is consumed -> one barrier per tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KB * DH * 2];
+    constexpr int STAGE_B = 2 * KB * DH * 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #define ATTN_KWRITE(KR, I)                                                                 \
     {                                                                                      \
         const int key_ = kr + 16 * (I);                                                    \
-        *(uint4*)(Ks + key_ * 256 + ((kc ^ (key_ & 15)) << 4)) = KR;                       \
+        *(uint4*)(Ks_w + key_ * 256 + ((kc ^ (key_ & 15)) << 4)) = KR;                     \
     }
     // 4 keys x 2 d-values (one dword column J of the 4 loaded rows) -> two 8-byte V^T entries
 #define ATTN_VWRITE(J, C)                                                                  \
@@ -120,11 +120,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         ev.y = (vreg2.C & 0xffffu) | (vreg3.C << 16);                                      \
         od.x = (vreg0.C >> 16) | (vreg1.C & 0xffff0000u);                                  \
         od.y = (vreg2.C >> 16) | (vreg3.C & 0xffff0000u);                                  \
-        *(uint2*)(Vt + d_even * 128 + ((vm ^ ((d_even >> 1) & 15)) << 3)) = ev;            \
-        *(uint2*)(Vt + d_odd * 128 + ((vm ^ ((d_odd >> 1) & 15)) << 3)) = od;              \
+        *(uint2*)(Vt_w + d_even * 128 + ((vm ^ ((d_even >> 1) & 15)) << 3)) = ev;          \
+        *(uint2*)(Vt_w + d_odd * 128 + ((vm ^ ((d_odd >> 1) & 15)) << 3)) = od;            \
     }
-#define ATTN_WRITE_LDS()                                                                   \
+#define ATTN_WRITE_LDS(STAGE)                                                              \
     {                                                                                      \
+        unsigned char* Ks_w = smem + (STAGE) * STAGE_B;                                    \
+        unsigned char* Vt_w = Ks_w + KB * DH * 2;                                          \
         ATTN_KWRITE(kreg0, 0) ATTN_KWRITE(kreg1, 1) ATTN_KWRITE(kreg2, 2) ATTN_KWRITE(kreg3, 3) \
         ATTN_VWRITE(0, x) ATTN_VWRITE(1, y) ATTN_VWRITE(2, z) ATTN_VWRITE(3, w)            \
     }
@@ -148,11 +150,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float l_run = 0.f;           // this lane's share of the running denominator
 
     ATTN_ISSUE_LOADS(0)
+    ATTN_WRITE_LDS(0)
+    if (n_tiles > 1) ATTN_ISSUE_LOADS(1)
+    __syncthreads();
     for (int tile = 0; tile < n_tiles; ++tile) {
         const int64_t k0 = (int64_t)tile * KB;
-        ATTN_WRITE_LDS()
-        __syncthreads();
-        if (tile + 1 < n_tiles) ATTN_ISSUE_LOADS(tile + 1)
+        const int cur = tile & 1;
+        // stage cur^1 was last read before the previous barrier: refill it with tile+1 (its global loads were
+        // issued one iteration ago) and put tile+2's loads in flight, all under this tile's math
+        if (tile + 1 < n_tiles) {
+            ATTN_WRITE_LDS(cur ^ 1)
+            if (tile + 2 < n_tiles) ATTN_ISSUE_LOADS(tile + 2)
+        }
+        const unsigned char* Ks = smem + cur * STAGE_B;
+        const unsigned char* Vt = Ks + KB * DH * 2;
 
         if (k0 <= wq_last) {                       // wave-uniform: at least one visible key
             // ---- S^T = K . Q^T -----------------------------------------------------------------------------
@@ -202,11 +213,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                     pk[kt][r >> 1] = pack_bf2(p0, p1);
                 }
             l_run = fmaf(l_run, alpha, psum);
+            const float m_run_prev = m_run;
             m_run = m_new;
+            if (__any(m_new > m_run_prev)) {          // wave-uniform: late in a long row nothing moves any more
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) oacc[dt] = oacc[dt] * alpha;
+            }
             // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
