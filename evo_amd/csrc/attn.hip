@@ -35,8 +35,18 @@ struct AttnArgs {
     int H;
     float scale_log2;      // softmax_scale * log2(e)
     int n_qblocks;
+    // decode (split-K) mode only
+    const int64_t* dyn_pos;   // device scalar: position of the (single) query; overrides Tk / q_pos0 when non-null
+    float* part_o;            // [B, H, n_splits, 128] unnormalised partial outputs
+    float* part_ml;           // [B, H, n_splits, 2]   running max (log2 domain) and denominator
+    int n_splits;
 };
 
+// DECODE = true: one query row per (batch, head); blockIdx.x is a SPLIT of the key range ("flash-decoding"):
+// every split streams its share of the KV cache and leaves an unnormalised partial (O, m, l) that
+// attn_decode_combine_kernel merges.  The key count may come from device memory (dyn_pos), so the launch is
+// position-independent and can sit inside a captured hipGraph.
+template <bool DECODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // two stages of {Ks 16 KiB, Vt 16 KiB}: tile t+1 is written while tile t is consumed -> one barrier per tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KB * DH * 2];
@@ -48,7 +58,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
-    const int qb = a.n_qblocks - 1 - (int)blockIdx.x;      // longest (latest) query blocks first
+    int64_t Tk_ = a.Tk, q_pos0_ = a.q_pos0;
+    if (DECODE && a.dyn_pos) { q_pos0_ = a.dyn_pos[0]; Tk_ = q_pos0_ + a.Tq; }
+    const int qb = DECODE ? 0 : a.n_qblocks - 1 - (int)blockIdx.x;      // longest (latest) query blocks first
     const int head = blockIdx.y;
     const int bat = blockIdx.z;
     const int64_t q0 = (int64_t)qb * QB;
@@ -70,12 +82,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // ---- key range of this workgroup / wave -------------------------------------------------------------
     int64_t q_last = q0 + QB - 1;
     if (q_last > a.Tq - 1) q_last = a.Tq - 1;
-    int64_t max_key = q_last + a.q_pos0;
-    if (max_key > a.Tk - 1) max_key = a.Tk - 1;
+    int64_t max_key = q_last + q_pos0_;
+    if (max_key > Tk_ - 1) max_key = Tk_ - 1;
     const int n_tiles = (int)(max_key / KB) + 1;
-    const int64_t wq_first = q0 + wave * 32 + a.q_pos0;          // position limit of the wave's first row
+    int tile_begin = 0, tile_end = n_tiles;
+    if (DECODE) {
+        const int per = (n_tiles + a.n_splits - 1) / a.n_splits;
+        tile_begin = (int)blockIdx.x * per;
+        tile_end = tile_begin + per < n_tiles ? tile_begin + per : n_tiles;
+    }
+    const int64_t wq_first = q0 + wave * 32 + q_pos0_;           // position limit of the wave's first row
     const int64_t wq_last = wq_first + 31;
-    const int64_t my_lim = qrow + a.q_pos0;                       // this lane's query sees keys <= my_lim
+    const int64_t my_lim = qrow + q_pos0_;                        // this lane's query sees keys <= my_lim
 
     // ---- staging maps ------------------------------------------------------------------------------------
     const int kc = tid & 15;             // K: 16-byte chunk of the row
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #define ATTN_ISSUE_LOADS(TILE)                                                             \
     {                                                                                      \
         const int64_t k0_ = (int64_t)(TILE) * KB;                                          \
-        const int64_t left_ = a.Tk - 1 - k0_;                                              \
+        const int64_t left_ = Tk_ - 1 - k0_;                                               \
         const int rel_max_ = left_ < KB - 1 ? (int)left_ : KB - 1;                         \
         const unsigned char* kb_ = (const unsigned char*)(kp + k0_ * a.k_st);              \
         const unsigned char* vb_ = (const unsigned char*)(vp + k0_ * a.v_st);              \
@@ -149,18 +167,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float m_run = -INFINITY;     // running max (scaled, log2 domain)
     float l_run = 0.f;           // this lane's share of the running denominator
 
-    ATTN_ISSUE_LOADS(0)
-    ATTN_WRITE_LDS(0)
-    if (n_tiles > 1) ATTN_ISSUE_LOADS(1)
+    if (tile_begin < tile_end) {
+        ATTN_ISSUE_LOADS(tile_begin)
+        ATTN_WRITE_LDS(0)
+        if (tile_begin + 1 < tile_end) ATTN_ISSUE_LOADS(tile_begin + 1)
+    }
     __syncthreads();
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int64_t k0 = (int64_t)tile * KB;
-        const int cur = tile & 1;
+        const int cur = (tile - tile_begin) & 1;
         // stage cur^1 was last read before the previous barrier: refill it with tile+1 (its global loads were
         // issued one iteration ago) and put tile+2's loads in flight, all under this tile's math
-        if (tile + 1 < n_tiles) {
+        if (tile + 1 < tile_end) {
             ATTN_WRITE_LDS(cur ^ 1)
-            if (tile + 2 < n_tiles) ATTN_ISSUE_LOADS(tile + 2)
+            if (tile + 2 < tile_end) ATTN_ISSUE_LOADS(tile + 2)
         }
         const unsigned char* Ks = smem + cur * STAGE_B;
         const unsigned char* Vt = Ks + KB * DH * 2;
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
             // ---- online softmax (this lane = one query row, 32 of the tile's 64 keys) --------------------
-            const bool need_mask = (k0 + KB - 1 > wq_first) || (k0 + KB > a.Tk);
+            const bool need_mask = (k0 + KB - 1 > wq_first) || (k0 + KB > Tk_);
             float tmax = -INFINITY;
             if (need_mask) {
 #pragma unroll
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t kidx = k0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const bool ok = (kidx <= my_lim) && (kidx < a.Tk);
+                        const bool ok = (kidx <= my_lim) && (kidx < Tk_);
                         sacc[kt][r] = ok ? sacc[kt][r] : -INFINITY;
                     }
             }
@@ -245,6 +265,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     // ---- epilogue: normalise and store O[q][d] -----------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (DECODE) {                                   // partial result of this split for query row 0
+        if (wave == 0 && l31 == 0) {
+            const int64_t slot = ((int64_t)bat * a.H + head) * a.n_splits + blockIdx.x;
+            float* po = a.part_o + slot * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(po + 32 * dt + 8 * g + 4 * half) =
+                        make_float4(oacc[dt][4 * g], oacc[dt][4 * g + 1], oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]);
+            if (half == 0) { a.part_ml[slot * 2] = m_run; a.part_ml[slot * 2 + 1] = l_tot; }
+        }
+        return;
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < a.Tq) {
         uint16_t* orow = a.o + ((int64_t)(bat * a.Tq + qrow) * a.H + head) * DH;
@@ -260,14 +294,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// merge the splits of one (batch, head): out[d] = sum_s O_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+                                                                  const float* __restrict__ part_ml,
+                                                                  uint16_t* __restrict__ o, int H, int n_splits) {
+    const int d = threadIdx.x, head = blockIdx.x, bat = blockIdx.y;
+    const int64_t base = ((int64_t)bat * H + head) * n_splits;
+    float M = -INFINITY;
+    for (int s = 0; s < n_splits; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < n_splits; ++s) {
+        const float m = part_ml[(base + s) * 2];
+        if (m == -INFINITY) continue;
+        const float w = __builtin_amdgcn_exp2f(m - M);
+        L = fmaf(part_ml[(base + s) * 2 + 1], w, L);
+        acc = fmaf(part_o[(base + s) * DH + d], w, acc);
+    }
+    o[((int64_t)bat * H + head) * DH + d] = f_to_bf(L > 0.f ? acc / L : 0.f);
+}
+
+static int attn_check_strides(int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                              int64_t v_sb, int64_t v_st, int64_t v_sh) {
+    return ((q_st % 8) || (k_st % 8) || (v_st % 8) || (q_sh % 8) || (k_sh % 8) || (v_sh % 8) || (q_sb % 8) ||
+            (k_sb % 8) || (v_sb % 8)) ? -1 : 0;      // 16-byte row accesses
+}
+
 extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H,
                                         int64_t Tq, int64_t Tk, int64_t q_pos0, int64_t q_sb, int64_t q_st,
                                         int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh, int64_t v_sb,
                                         int64_t v_st, int64_t v_sh, float softmax_scale, void* stream) {
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || q_pos0 < 0) return -1;
-    if ((q_st % 8) || (k_st % 8) || (v_st % 8) || (q_sh % 8) || (k_sh % 8) || (v_sh % 8) || (q_sb % 8) || (k_sb % 8) ||
-        (v_sb % 8))
-        return -1;   // 16-byte row accesses
+    if (attn_check_strides(q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh)) return -1;
     if (H > 65535 || B > 65535) return -1;
     AttnArgs a;
     a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (uint16_t*)o;
@@ -277,6 +334,32 @@ extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void
     a.H = (int)H;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     a.n_qblocks = (int)((Tq + QB - 1) / QB);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.n_qblocks, (unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    a.dyn_pos = nullptr; a.part_o = nullptr; a.part_ml = nullptr; a.n_splits = 1;
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(a.n_qblocks, (unsigned)H, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return evo_launch_status();
+}
+
+extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H,
+                                    int64_t Tk, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_st,
+                                    int64_t k_sh, int64_t v_sb, int64_t v_st, int64_t v_sh, const int64_t* dyn_pos,
+                                    float* part_o, float* part_ml, int64_t n_splits, float softmax_scale,
+                                    void* stream) {
+    if (B <= 0 || H <= 0 || Tk <= 0 || n_splits <= 0 || n_splits > 1024 || !part_o || !part_ml) return -1;
+    if (attn_check_strides(q_sb, 8, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh)) return -1;
+    if (H > 65535 || B > 65535) return -1;
+    AttnArgs a;
+    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.o = (uint16_t*)o;
+    a.Tq = 1; a.Tk = Tk; a.q_pos0 = Tk - 1;
+    a.q_sb = q_sb; a.q_st = 0; a.q_sh = q_sh; a.k_sb = k_sb; a.k_st = k_st; a.k_sh = k_sh;
+    a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
+    a.H = (int)H;
+    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    a.n_qblocks = 1;
+    a.dyn_pos = dyn_pos; a.part_o = part_o; a.part_ml = part_ml; a.n_splits = (int)n_splits;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)n_splits, (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(128), 0, s, part_o, part_ml,
+                       (uint16_t*)o, (int)H, (int)n_splits);
     return evo_launch_status();
 }

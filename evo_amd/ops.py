@@ -32,6 +32,8 @@ _SIGNATURES = {
     "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR], _c.c_int),
+    "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
+    "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -157,7 +159,9 @@ class HipOps:
 
     # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16."""
+        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 8 (decode) takes the weight-streaming kernel."""
+        if x.shape[0] <= self.SMALL_M and self._small_m_ok(x, w):
+            return self._linear_small_m(x, w, b, None)
         with self._t("gemm"):
             if b is not None:
                 return torch.addmm(b, x, w.t())
@@ -165,8 +169,26 @@ class HipOps:
 
     def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         """res += x @ w^T (fp32 accumulate, one rounding), in place."""
+        if x.shape[0] <= self.SMALL_M and self._small_m_ok(x, w) and res.is_contiguous():
+            return self._linear_small_m(x, w, None, res)
         with self._t("gemm"):
             return res.addmm_(x, w.t())
+
+    SMALL_M = 8
+
+    @staticmethod
+    def _small_m_ok(x, w):
+        return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
+                and w.is_contiguous() and x.shape[1] % 8 == 0 and x.shape[0] >= 1)
+
+    def _linear_small_m(self, x, w, b, res):
+        M, K = x.shape
+        N = w.shape[0]
+        y = res if res is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        with self._t("gemv"):
+            _check(self.lib.evo_linear_small_m_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(res), y.data_ptr(),
+                                                    M, N, K, _stream()), "evo_linear_small_m_bf16")
+        return y
 
     # ---- kernels -------------------------------------------------------------------------------------
     def embed(self, ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -327,6 +349,30 @@ class HipOps:
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
                 q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                 v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _stream()), "evo_attn_fwd_causal_bf16")
+        return o
+
+    def attention_decode(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                         pos: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
+        """One query per sequence against the KV cache: q [B,1,H,128]; k/v [B,Tk,H,128] views.  With `pos`
+        (device int64 scalar) the query sits at pos and sees keys [0,pos]; Tk is then just the capacity."""
+        B, Tq, H, hd = q.shape
+        if Tq != 1 or hd != 128:
+            raise RuntimeError("attention_decode: expects [B,1,H,128] queries")
+        for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+            if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
+                raise RuntimeError(f"attention_decode {nm}: need a ROCm bf16 tensor with a dense last dim")
+        Tk = k.shape[1]
+        if n_splits is None:                     # enough workgroups to cover the chip, at most one per key tile
+            n_splits = max(1, min((Tk + 63) // 64, -(-512 // (B * H))))
+        o = torch.empty(B, 1, H, hd, dtype=torch.bfloat16, device=q.device)
+        part_o = torch.empty(B, H, n_splits, hd, dtype=torch.float32, device=q.device)
+        part_ml = torch.empty(B, H, n_splits, 2, dtype=torch.float32, device=q.device)
+        with self._t("attn_decode"):
+            _check(self.lib.evo_attn_decode_bf16(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tk, q.stride(0), q.stride(2),
+                k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2), _ptr(pos),
+                part_o.data_ptr(), part_ml.data_ptr(), n_splits, 1.0 / math.sqrt(hd), _stream()),
+                "evo_attn_decode_bf16")
         return o
 
     def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:

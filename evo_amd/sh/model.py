@@ -227,11 +227,25 @@ class StripedHyena(nn.Module):
         freqs = torch.outer(t, inv_freq)
         cos = torch.cos(freqs).to(torch.bfloat16).float().contiguous()
         sin = torch.sin(freqs).to(torch.bfloat16).float().contiguous()
-        if T > 1:                                  # decode steps are not worth caching
-            if len(self._rot_cache) > 8:
-                self._rot_cache.clear()
-            self._rot_cache[key] = (cos, sin)
+        if len(self._rot_cache) > 8:               # a decode step reuses its table for all attention layers
+            self._rot_cache.clear()
+        self._rot_cache[key] = (cos, sin)
         return cos, sin
+
+    def _rotary_dyn(self, pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Same table for ONE position held in device memory (int64 [1]) -- no host read, graph-capturable."""
+        hd = self.head_dim
+        dev = pos.device
+        inv = getattr(self, "_inv_freq_dev", None)
+        if inv is None or inv.device != dev:
+            inv = 1.0 / (self.rotary_base ** (torch.arange(0, hd, 2, dtype=torch.float32, device=dev) / hd))
+            self._inv_freq_dev = inv
+        t = pos.to(torch.float32)
+        if self.rotary_scaling != 1.0:
+            t = t / self.rotary_scaling
+        freqs = torch.outer(t, inv)
+        return (torch.cos(freqs).to(torch.bfloat16).float().contiguous(),
+                torch.sin(freqs).to(torch.bfloat16).float().contiguous())
 
     # ------------------------------------------------------------------ blocks
     def _mlp_residual_(self, blk, x2d, bias):
@@ -294,17 +308,29 @@ class StripedHyena(nn.Module):
         n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
         qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, T, 3, H, hd)
         off = int(cache.seqlen_offset) if cache is not None else 0
-        cos, sin = self._rotary(off, T, x2d.device)
-        ops.rope_(qkv, cos, sin)
+        pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]
-        if cache is not None:
-            kv = self._kv_buffer(cache, i, B, off + T, qkv)
-            kv[:B, off:off + T].copy_(qkv[:, :, 1:3])
-            k = kv[:B, : off + T, 0]
-            v = kv[:B, : off + T, 1]
+        if pos is not None and T == 1:
+            # position-independent decode step (hipGraph replay): the position lives in device memory
+            cos, sin = self._rotary_dyn(pos)
+            ops.rope_(qkv, cos, sin)
+            kv = cache.key_value_memory_dict[i][:B]
+            kv.index_copy_(1, pos, qkv[:, :, 1:3])
+            a = ops.attention_decode(q, kv[:, :, 0], kv[:, :, 1], pos=pos).view(B, D)
         else:
-            k, v = qkv[:, :, 1], qkv[:, :, 2]
-        a = ops.attention(q, k, v, off).view(B * T, D)
+            cos, sin = self._rotary(off, T, x2d.device)
+            ops.rope_(qkv, cos, sin)
+            if cache is not None:
+                kv = self._kv_buffer(cache, i, B, off + T, qkv)
+                kv[:B, off:off + T].copy_(qkv[:, :, 1:3])
+                k = kv[:B, : off + T, 0]
+                v = kv[:B, : off + T, 1]
+            else:
+                k, v = qkv[:, :, 1], qkv[:, :, 2]
+            if T == 1 and cache is not None:
+                a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
+            else:
+                a = ops.attention(q, k, v, off).view(B * T, D)
         ops.linear_residual_(x2d, a, mha.out_proj.weight)
         self._mlp_residual_(blk, x2d, mha.out_proj.bias)
 
@@ -336,9 +362,83 @@ class StripedHyena(nn.Module):
         if padding_mask is not None:
             raise NotImplementedError("padding_mask is not used on the evo path and is not supported")
         B, T = x.shape
+        if T == 1 and inference_params_dict is not None and self._graph_eligible(inference_params_dict):
+            logits = self._graph_decode_step(x, inference_params_dict)
+            if logits is not None:
+                return logits, inference_params_dict
         h = self.hidden_states(x, inference_params_dict)
         logits = self.ops.linear(h, self.unembed.weight, None).view(B, T, self.vocab_size)
         return logits, inference_params_dict
+
+    # ------------------------------------------------------------------ hipGraph-captured decode step
+    # One decode step is ~270 short launches (the reference pays that per token too); at batch 1 the step is
+    # launch-bound (5.2 ms against a 2.1 ms weight-streaming floor).  The step is therefore captured ONCE into a
+    # hipGraph whose kernels read the token position from device memory, and replayed for every token.
+    decode_graph = True          # set False (or EVO_AMD_DECODE_GRAPH=0) to run every decode step eagerly
+
+    def _graph_eligible(self, ipd) -> bool:
+        import os
+        if not self.decode_graph or os.environ.get("EVO_AMD_DECODE_GRAPH", "1") == "0":
+            return False
+        if getattr(self.ops, "name", "") != "hip-gfx950" or getattr(self.ops, "timer", None) is not None:
+            return False
+        hy, mha = ipd["hyena"], ipd["mha"]
+        # every layer must already hold state (i.e. a prefill happened), on this device
+        return all(i in hy.fir_state_dict for i in self.hyena_layer_idxs) and \
+            all(i in mha.key_value_memory_dict for i in self.attn_layer_idxs)
+
+    def _graph_decode_step(self, x, ipd):
+        mha = ipd["mha"]
+        B = x.shape[0]
+        off = int(mha.seqlen_offset)
+        st = getattr(self, "_dgraph", None)
+        key = (B, id(mha), id(ipd["hyena"]), str(self.device))
+        cap = min(mha.key_value_memory_dict[i].shape[1] for i in self.attn_layer_idxs) if self.attn_layer_idxs else 1 << 62
+        same_bufs = st is not None and st["key"] == key and all(
+            mha.key_value_memory_dict[i].data_ptr() == p for i, p in st["kv_ptrs"].items()) and all(
+            ipd["hyena"].state_dict[i].data_ptr() == p for i, p in st["st_ptrs"].items())
+        if off + 1 > cap or not same_bufs:
+            st = None
+            if off + 1 > cap or any(mha.key_value_memory_dict[i].shape[0] < B for i in self.attn_layer_idxs):
+                for i in self.attn_layer_idxs:      # grow outside the graph, with headroom for the tokens to come
+                    self._kv_buffer(mha, i, B, off + 1 + 4096, mha.key_value_memory_dict[i])
+        try:
+            if st is None:
+                if getattr(self, "_dgraph_warm", None) != key:
+                    self._dgraph_warm = key         # first step with these buffers runs eagerly (warms M=B GEMMs)
+                    self._dgraph = None
+                    return None
+                dev = self.device
+                st = {"key": key, "ids": torch.zeros(B, 1, dtype=torch.int64, device=dev),
+                      "pos": torch.zeros(1, dtype=torch.int64, device=dev),
+                      "kv_ptrs": {i: mha.key_value_memory_dict[i].data_ptr() for i in self.attn_layer_idxs},
+                      "st_ptrs": {i: ipd["hyena"].state_dict[i].data_ptr() for i in self.hyena_layer_idxs}}
+                st["ids"].copy_(x)
+                st["pos"].fill_(off)
+                mha.pos_tensor = st["pos"]
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g):
+                        h = self.hidden_states(st["ids"], ipd)
+                        st["logits"] = self.ops.linear(h, self.unembed.weight, None).view(B, 1, self.vocab_size)
+                        st["pos"].add_(1)
+                finally:
+                    mha.pos_tensor = None
+                st["graph"] = g
+                st["next"] = off
+                self._dgraph = st
+            st["ids"].copy_(x)
+            if st["next"] != off:
+                st["pos"].fill_(off)
+            st["graph"].replay()
+            st["next"] = off + 1
+            return st["logits"].clone()
+        except Exception as e:  # noqa: BLE001   capture is an optimisation: fall back to eager HIP launches
+            import warnings
+            warnings.warn(f"decode hipGraph disabled ({type(e).__name__}: {e}); continuing with eager launches")
+            self.decode_graph = False
+            self._dgraph = None
+            return None
 
     # upstream names, kept for callers that reach for them
     def stateless_forward(self, x, padding_mask=None):

@@ -110,6 +110,28 @@ int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* 
                              int64_t v_sb, int64_t v_st, int64_t v_sh,
                              float softmax_scale, void* stream);
 
+/* decode form (one query per sequence, Tq = 1): split-K over the key range ("flash-decoding") + combine.
+ * replaces flash_attn_with_kvcache                           [REF evo/generation.py:109-110,138-155]
+ *   q [B, 1, H, 128] (q_sb, q_sh strides), k/v views of the KV cache [B, cap, H, 128];
+ *   dyn_pos: NULL -> the query sits at position Tk-1 and sees keys [0, Tk);  non-NULL -> a device int64 scalar
+ *            p: the query sits at p and sees keys [0, p] (Tk is then only the cache capacity bound) -- the launch
+ *            no longer depends on the position, so a captured hipGraph can be replayed for every token;
+ *   part_o [B, H, n_splits, 128] f32 and part_ml [B, H, n_splits, 2] f32: caller-owned workspace. */
+int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
+                         int64_t B, int64_t H, int64_t Tk,
+                         int64_t q_sb, int64_t q_sh,
+                         int64_t k_sb, int64_t k_st, int64_t k_sh,
+                         int64_t v_sb, int64_t v_st, int64_t v_sh,
+                         const int64_t* dyn_pos, float* part_o, float* part_ml, int64_t n_splits,
+                         float softmax_scale, void* stream);
+
+/* ---- skinny dense layer (decode) ----------------------------------------------------------------------
+ * replaces cuBLAS GEMV-shaped nn.Linear calls of the single-token forward   [REF evo/generation.py:151-155]
+ * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 8, K % 8 == 0, all bf16,
+ * fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) form; `residual` may alias `y`. */
+int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                            int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ---- gated MLP activation ---------------------------------------------------------------------------
  * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]
  * g [M, 2*I] bf16 = [l1 x | l2 x]  ->  a [M, I] bf16 = gelu_erf(g[:, :I]) * g[:, I:]. */

@@ -75,3 +75,7 @@ class OracleOps:
     def hyena_stage2(self, z, fir_w, fir_b, poles, residues, dskip, n_heads, stage1, z_halo=None, s0=None):
         y, _ = R.op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo, s0)
         return self._o(y)
+
+    def attention_decode(self, q, k, v, pos=None, n_splits=None):
+        Tk = k.shape[1] if pos is None else int(pos.item()) + 1
+        return self._o(R.op_attention(q, k[:, :Tk], v[:, :Tk], Tk - 1))

@@ -256,3 +256,18 @@ def test_attention_4k_causal(ops):
     v = bf(torch.randn(B, T, H, 128, generator=gen(29)))
     o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
     assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ decode attention
+@pytest.mark.parametrize("B,H,Tk,splits", [(1, 2, 1, None), (2, 2, 300, None), (1, 4, 8193, 8), (3, 2, 700, 1), (1, 2, 130, 5)])
+def test_attention_decode_matches_oracle(ops, B, H, Tk, splits):
+    q = bf(torch.randn(B, 1, H, 128, generator=gen(30)))
+    kv = bf(torch.randn(B, Tk + 37, 2, H, 128, generator=gen(31)))           # cache with slack past Tk
+    ref = R.op_attention(q, kv[:, :Tk, 0], kv[:, :Tk, 1], Tk - 1)
+    kvd = kv.to(DEV)
+    o = ops.attention_decode(q.to(DEV), kvd[:, :Tk, 0], kvd[:, :Tk, 1], n_splits=splits)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
+    # position read from device memory (the hipGraph form): keys [0, pos] of the full-capacity view
+    pos = torch.tensor([Tk - 1], dtype=torch.int64, device=DEV)
+    o2 = ops.attention_decode(q.to(DEV), kvd[:, :, 0], kvd[:, :, 1], pos=pos, n_splits=splits)
+    assert_close_bf16(o2, ref, rl2=4e-3, atol=2e-2)
