@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--nt", type=int, default=8192)
     ap.add_argument("--skip-131k", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-gen", action="store_true")
     ap.add_argument("--steps-131k", type=int, default=2)
     args = ap.parse_args()
 
@@ -190,6 +191,13 @@ def main():
         except Exception as e:  # noqa: BLE001  (report, never hide)
             out["ctx131k"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ------------------------------------------------------------------ generation (BASELINE configs[4]), N = 1 only
+    if n_gpus == 1 and not args.skip_gen:
+        try:
+            out["generation"] = bench_generation(device)
+        except Exception as e:  # noqa: BLE001
+            out["generation"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline()
@@ -197,6 +205,37 @@ def main():
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
+
+
+def bench_generation(device, prompt=8192, new=256):
+    """evo-1-131k-base, 8,192-nt prompt -> `new` greedy tokens, batch 1: full-prompt parallel prefill (exact carried
+    Hyena state + KV cache), then the recurrent decode step (hipGraph-captured, weight-streaming GEMV)."""
+    from evo_amd.generation import Generator
+    from evo_amd.tokenizer import CharLevelTokenizer
+    model = build_model("evo-1-131k-base", device)
+    ids = acgt_ids(1, prompt, 777, device)[:, 1:]                    # no BOS: generate()'s default
+    g = Generator(model, CharLevelTokenizer(512), top_k=1, top_p=1.0, temperature=1.0)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.generate(device=device, input_ids=ids, num_tokens=n, cached_generation=True, print_generation=False,
+                   stop_at_eos=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(3)
+    t_pre = min(run(1) for _ in range(2))
+    t_all = run(1 + new)
+    dec = (t_all - t_pre) / new
+    res = {"config": {"workload": f"evo-1-131k-base generation, {prompt}-nt prompt -> {new} new tokens, batch 1, greedy"},
+           "prefill_ms": t_pre * 1e3, "prefill_nt_per_s": prompt / t_pre, "decode_ms_per_token": dec * 1e3,
+           "decode_tokens_per_s": 1.0 / dec,
+           "weight_stream_GBps": 12.906 / dec, "hbm_frac": 12.906e9 / dec / 1e9 / HBM_PEAK_GBS,
+           "graph_engaged": getattr(model, "_dgraph", None) is not None}
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def bench_131k(args, device, rank, world, dist_on, ops):

@@ -93,7 +93,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
 template <int M>
 static void gemv_launch(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t N, int64_t K,
                         hipStream_t s) {
-    constexpr int R = M <= 2 ? 4 : 2;
+    // rows per wave.  Measured (tools/bench_gemv.py, MI355X): R=4 wins for every M (R=8 starves the chip of
+    // waves at N=4096; R=2 doubles the L2 re-reads of x): 4.9-5.4 TB/s at M=1-2, 3.0-3.6 TB/s at M=8.
+#ifndef GEMV_R_A
+#define GEMV_R_A 4
+#endif
+#ifndef GEMV_R_B
+#define GEMV_R_B 4
+#endif
+#ifndef GEMV_R_C
+#define GEMV_R_C 4
+#endif
+    constexpr int R = M <= 2 ? GEMV_R_A : (M <= 4 ? GEMV_R_B : GEMV_R_C);
     const int64_t waves = (N + R - 1) / R;
     hipLaunchKernelGGL((gemv_kernel<M, R>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)x,
                        (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));

@@ -160,7 +160,7 @@ class HipOps:
     # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 8 (decode) takes the weight-streaming kernel."""
-        if x.shape[0] <= self.SMALL_M and self._small_m_ok(x, w):
+        if self._use_small_m(x, w):
             return self._linear_small_m(x, w, b, None)
         with self._t("gemm"):
             if b is not None:
@@ -169,17 +169,20 @@ class HipOps:
 
     def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         """res += x @ w^T (fp32 accumulate, one rounding), in place."""
-        if x.shape[0] <= self.SMALL_M and self._small_m_ok(x, w) and res.is_contiguous():
+        if self._use_small_m(x, w) and res.is_contiguous():
             return self._linear_small_m(x, w, None, res)
         with self._t("gemm"):
             return res.addmm_(x, w.t())
 
-    SMALL_M = 8
-
     @staticmethod
-    def _small_m_ok(x, w):
+    def _use_small_m(x, w):
+        """Measured crossover (tools/bench_gemv.py): the streaming kernel beats hipBLASLt for M <= 4 on every
+        layer shape, and for M <= 8 on the N <= 4096 layers (out / l3 / unembed)."""
+        M = x.shape[0]
+        if not (1 <= M <= 8 and (M <= 4 or w.shape[0] <= 4096)):
+            return False
         return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
-                and w.is_contiguous() and x.shape[1] % 8 == 0 and x.shape[0] >= 1)
+                and w.is_contiguous() and x.shape[1] % 8 == 0)
 
     def _linear_small_m(self, x, w, b, res):
         M, K = x.shape
