@@ -80,6 +80,17 @@ def timed(fn, steps, warmup, dist_on):
     return dt
 
 
+def pmc_traffic(kernel, B, T):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, see
+    profiles/r01_ops_pmc_fetch_write.txt); None for shapes that were not profiled.  PMC counters cannot be
+    collected from inside this process, so this is a recorded measurement, not a live one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get(f"B{B}_T{T}")
+    except (OSError, ValueError):
+        return None
+
+
 def flops_per_token(T):
     """GEMM 12.889 GF + unembed 4.19 MF + causal attention 24,576*T."""
     return 32 * 402_784_256 + 2 * 4096 * 512 + 24_576 * T
@@ -163,7 +174,7 @@ def main():
     op_ms = apply_ms + ksum["hyena_seg_state"][1] + ksum["hyena_carry_scan"][1]
     achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
     roofline = {"kernel": "hyena_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("hyena_apply_kernel", B, T),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
                 "operator_3_launch_ms": op_ms, "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     attn_flops = B * 4 * D * T * T / 2                    # causal QK^T + PV per layer
@@ -274,6 +285,7 @@ def bench_131k(args, device, rank, world, dist_on, ops):
            "roofline": {"kernel": "hyena_apply_kernel", "bound": "hbm",
                         "achieved": alg_bytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic("hyena_apply_kernel", B, Tl) if world == 1 else None,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
                         "operator_3_launch_ms": op_ms,
                         "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
