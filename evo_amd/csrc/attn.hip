@@ -47,7 +47,7 @@ struct AttnArgs {
 // attn_decode_combine_kernel merges.  The key count may come from device memory (dyn_pos), so the launch is
 // position-independent and can sit inside a captured hipGraph.
 template <bool DECODE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
     // two stages of {Ks 16 KiB, Vt 16 KiB}: tile t+1 is written while tile t is consumed -> one barrier per tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KB * DH * 2];
     constexpr int STAGE_B = 2 * KB * DH * 2;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         if (k0 <= wq_last) {                       // wave-uniform: at least one visible key
             // ---- S^T = K . Q^T -----------------------------------------------------------------------------
             f32x16_t sacc[2];
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -200,17 +201,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                     sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf), as_frag(qf[ks]), sacc[kt], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             // ---- online softmax (this lane = one query row, 32 of the tile's 64 keys) --------------------
             const bool need_mask = (k0 + KB - 1 > wq_first) || (k0 + KB > Tk_);
             float tmax = -INFINITY;
-            if (need_mask) {
+            if (need_mask) {                       // 32-bit tile-relative limits (diagonal / ragged tiles only)
+                const int64_t lim64 = (my_lim < Tk_ - 1 ? my_lim : Tk_ - 1) - k0;
+                const int lim = lim64 > 63 ? 63 : (lim64 < -1 ? -1 : (int)lim64);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int64_t kidx = k0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const bool ok = (kidx <= my_lim) && (kidx < Tk_);
-                        sacc[kt][r] = ok ? sacc[kt][r] : -INFINITY;
+                        const int kidx = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        sacc[kt][r] = kidx <= lim ? sacc[kt][r] : -INFINITY;
                     }
             }
 #pragma unroll
@@ -221,17 +224,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const float m_new = fmaxf(m_run, tmax * a.scale_log2);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run = -inf -> 0
-            float psum = 0.f;
+            // p = 2^(s*c - m): scale/subtract and the row sum run two scores per instruction (v_pk_fma_f32 /
+            // v_pk_add_f32); only the exponentials are scalar
+            const f32x2_t c2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
+            f32x2_t psum2 = {0.f, 0.f};
             uint32_t pk[2][8];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], a.scale_log2, -m_use));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r + 1], a.scale_log2, -m_use));
-                    psum += p0 + p1;
-                    pk[kt][r >> 1] = pack_bf2(p0, p1);
+                    const f32x2_t s2 = {sacc[kt][r], sacc[kt][r + 1]};
+                    const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);
+                    const f32x2_t p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                    psum2 += p2;
+                    pk[kt][r >> 1] = pack_bf2(p2[0], p2[1]);
                 }
+            const float psum = psum2[0] + psum2[1];
             l_run = fmaf(l_run, alpha, psum);
             const float m_run_prev = m_run;
             m_run = m_new;
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int dt = 0; dt < 4; ++dt) oacc[dt] = oacc[dt] * alpha;
             }
             // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf), as_frag(pf), oacc[dt], 0, 0, 0);
                     }
                 }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
     }

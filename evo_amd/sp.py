@@ -10,13 +10,18 @@ GEMM, the MLP, the unembedding and the scoring tail are token-local -> no commun
                 (3) all-gather of the R end states (262 KB * B per rank: latency-, not bandwidth-bound)
                 (4) S_in(r) = sum_{q<r} p^{Tl*(r-1-q)} E_q   (exact: the filter is a finite sum of modes)
                 (5) stage 2: carry-add + apply kernel
-  Attention     K,V of the shard are all-gathered (token-major layout so the gathered buffer is directly
-                addressable by the attention kernel's strides); queries attend keys <= their position.  The
-                gathers are issued per batch row and asynchronously, so row b's attention overlaps the
-                transfers of rows b+1.. on the collective stream.
+  Attention     head <-> sequence all-to-all ("Ulysses") when n_heads % R == 0: every rank sends, per batch row,
+                the q,k,v of its token shard for head group g to rank g and receives the FULL sequence for its
+                own H/R heads; it runs ordinary causal attention on them (perfectly balanced: no causal
+                last-rank penalty) and a second all-to-all returns the outputs to the token owners.  Rows are
+                pipelined: all forward exchanges are issued asynchronously up front, row b's attention
+                overlaps the transfers of rows b+1.., and its return exchange overlaps row b+1's attention.
+                Fallback (n_heads % R != 0): all-gather of K,V in token-major layout, queries attend keys <=
+                their position.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): the per-layer volumes above are 1.88 GB*B of K/V per
-attention layer (3 of 32 layers) and < 0.4 MB*B per Hyena layer.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so volume per rank matters: per attention layer and
+batch row the all-to-all moves 7/8 * (3+1) * Tl * D * 2 B = 0.47 GB (T = 131k, R = 8) against 1.88 GB received by
+a K/V all-gather; a Hyena layer moves < 0.4 MB per row.
 """
 from __future__ import annotations
 
@@ -51,12 +56,20 @@ class DistComm:
             w = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=async_op)
         return out, (w if async_op else _Done())
 
+    def all_to_all(self, t: torch.Tensor, async_op: bool = False):
+        """t [R, ...]: slice g goes to rank g; returns ([R, ...] with slice q received from rank q, work)."""
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        w = dist.all_to_all_single(out, t, group=self.group, async_op=async_op)
+        return out, (w if async_op else _Done())
+
 
 class SequenceParallelScorer:
     def __init__(self, model: StripedHyena, rank: int, world: int, group=None, comm=None):
         self.m = model
         self.rank, self.world = rank, world
         self.comm = comm if comm is not None else DistComm(group)
+        self.attn_mode = "auto"          # "auto": Ulysses when n_heads % world == 0, else K/V all-gather
         self._pow_cache = {}
 
     def _gather0(self, t: torch.Tensor, async_op: bool = False):
@@ -109,7 +122,7 @@ class SequenceParallelScorer:
         ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
         m._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
 
-    def _attn_block(self, blk, x2d, B, Tloc, Tl, t0):
+    def _attn_block(self, blk, x2d, B, Tloc, Tl, t0, T):
         m, ops = self.m, self.m.ops
         D, H, hd = m.hidden_size, m.num_heads, m.head_dim
         mha = blk.inner_mha_cls
@@ -117,6 +130,43 @@ class SequenceParallelScorer:
         qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, Tloc, 3, H, hd)
         cos, sin = m._rotary(t0, Tloc, x2d.device)
         ops.rope_(qkv, cos, sin)
+        if self.attn_mode != "allgather" and H % self.world == 0 and hasattr(self.comm, "all_to_all"):
+            a = self._attn_ulysses(qkv, B, Tloc, Tl, T)
+        else:
+            a = self._attn_allgather(qkv, B, Tloc, Tl, t0)
+        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight)
+        m._mlp_residual_(blk, x2d, mha.out_proj.bias)
+
+    def _attn_ulysses(self, qkv, B, Tloc, Tl, T):
+        ops, R = self.m.ops, self.world
+        H, hd = self.m.num_heads, self.m.head_dim
+        Hr = H // R
+        fwd = []
+        for b in range(B):                                   # [Tl, 3, R, Hr, hd] -> [R, Tl, 3, Hr, hd]: slice g -> rank g
+            x = qkv[b].view(Tloc, 3, R, Hr, hd)
+            send = x.new_zeros(R, Tl, 3, Hr, hd)
+            send[:, :Tloc] = x.permute(2, 0, 1, 3, 4)
+            fwd.append(self.comm.all_to_all(send, async_op=True))
+        back = []
+        for b in range(B):
+            recv, w = fwd[b]
+            w.wait()
+            full = recv.view(R * Tl, 3, Hr, hd)[None]        # the whole (padded) sequence, this rank's heads
+            o = ops.attention(full[:, :T, 0], full[:, :T, 1], full[:, :T, 2], 0)           # [1, T, Hr, hd]
+            ret = o.new_zeros(R * Tl, Hr, hd)
+            ret[:T] = o[0]
+            back.append(self.comm.all_to_all(ret.view(R, Tl, Hr, hd), async_op=True))     # slice q -> token owner q
+            fwd[b] = None
+        a = torch.empty(B, Tloc, H, hd, dtype=qkv.dtype, device=qkv.device)
+        for b in range(B):
+            recv, w = back[b]
+            w.wait()
+            a[b] = recv[:, :Tloc].permute(1, 0, 2, 3).reshape(Tloc, H, hd)                 # [R(head group), Tl, Hr, hd]
+        return a
+
+    def _attn_allgather(self, qkv, B, Tloc, Tl, t0):
+        ops = self.m.ops
+        H, hd = self.m.num_heads, self.m.head_dim
         # K,V per batch row, padded to Tl tokens, gathered asynchronously: [R, Tl, 2, H, hd] == tokens 0..R*Tl-1
         works, bufs = [], []
         for b in range(B):
@@ -132,8 +182,7 @@ class SequenceParallelScorer:
             works[b].wait()
             kvg = bufs[b].view(self.world * Tl, 2, H, hd)[:n_keys]
             a[b:b + 1] = ops.attention(qkv[b:b + 1, :, 0], kvg[None, :, 0], kvg[None, :, 1], t0)
-        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight)
-        m._mlp_residual_(blk, x2d, mha.out_proj.bias)
+        return a
 
     # ------------------------------------------------------------------ forward / scoring
     @torch.no_grad()
@@ -151,7 +200,7 @@ class SequenceParallelScorer:
         h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight)
         for blk in m.blocks:
             if isinstance(blk, _AttentionBlock):
-                self._attn_block(blk, h, B, Tloc, Tl, t0)
+                self._attn_block(blk, h, B, Tloc, Tl, t0, T)
             else:
                 self._hyena_block(blk, h, B, Tloc, Tl)
         if m.norm is not None:

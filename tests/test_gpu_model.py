@@ -41,6 +41,7 @@ def acgt(B, L, seed=1234):
 
 
 SMALL = dict(vocab_size=512, hidden_size=256, num_layers=4, attn_layer_idxs=[2], num_attention_heads=2)
+SMALL4 = dict(vocab_size=512, hidden_size=512, num_layers=4, attn_layer_idxs=[1], num_attention_heads=4)
 
 
 def test_native_library_is_what_runs():
@@ -164,12 +165,17 @@ class _ThreadComm:
         self.bar.wait()
         return out, _ThreadComm._W()
 
+    def all_to_all(self, t, async_op=False):
+        g, w = self.all_gather(t)                      # [R(src), R(dst), ...] -> take what every src sent to me
+        return g[:, self.local.rank].contiguous(), w
+
 
 @pytest.mark.parametrize("world,L", [(2, 700), (4, 1001)])
 def test_sequence_parallel_virtual_ranks_on_hip(world, L):
     import threading
     from evo_amd.sp import SequenceParallelScorer
-    cfgd = dict(SMALL, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+    # world 2 on a 2-head model and world 4 on a 4-head model take the Ulysses path (heads % world == 0)
+    cfgd = dict(SMALL if world == 2 else SMALL4, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
     cfg, sd, m = build(cfgd)
     m._pack()
     ids = acgt(2, L).to(DEV)

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, T, B, out_q):
+def _worker(rank, world, port, T, B, out_q, attn_mode="auto"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
@@ -37,6 +37,7 @@ def _worker(rank, world, port, T, B, out_q):
         ids = torch.randint(0, 512, (B, T), generator=torch.Generator().manual_seed(11))
         ids[:, 0] = 0
         sp = SequenceParallelScorer(m, rank, world)
+        sp.attn_mode = attn_mode
         local = sp.forward_local(ids)
         _, t0, t1 = sp.shard(T)
         full = m(ids)[0]
@@ -50,12 +51,17 @@ def _worker(rank, world, port, T, B, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,T,B", [(2, 37, 2), (3, 41, 1), (2, 5, 1)])
-def test_sequence_parallel_matches_unsharded(world, T, B):
+@pytest.mark.parametrize("world,T,B,attn_mode", [
+    (2, 37, 2, "auto"),          # 2 heads / 2 ranks: Ulysses head<->sequence all-to-all
+    (2, 37, 2, "allgather"),     # same split through the K/V all-gather fallback
+    (3, 41, 1, "auto"),          # 2 heads / 3 ranks: falls back to all-gather; ragged last shard
+    (2, 5, 1, "auto"),           # shards shorter than the FIR halo
+])
+def test_sequence_parallel_matches_unsharded(world, T, B, attn_mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, T, B, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, B, q, attn_mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
