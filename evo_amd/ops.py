@@ -294,22 +294,6 @@ class HipOps:
                                             y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
         return y
 
-    def hyena_end_state(self, z, fir_w, fir_b, poles, n_heads, z_halo=None, seg_len=None):
-        """State after the last token of z from a ZERO entering state (sequence-parallel pass 1)."""
-        B, T, D3 = z.shape
-        D = D3 // 3
-        C = seg_len or self.seg_len_override or pick_segment_length(B, T, n_heads)
-        n_seg = (T + C - 1) // C
-        agg = torch.empty(B, n_seg, D, 8, 2, dtype=torch.float32, device=z.device)
-        s_final = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
-        st = _stream()
-        _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                            poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
-               "evo_hyena_seg_state")
-        _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), None, s_final.data_ptr(), B, T, D, C,
-                                             st), "evo_hyena_carry_scan")
-        return torch.view_as_complex(s_final)
-
     def hyena_step(self, z_t: torch.Tensor, fir_state: torch.Tensor, iir_state: torch.Tensor, fir_w, fir_b, poles,
                    residues, dskip, n_heads: int) -> torch.Tensor:
         """One decode step; fir_state [B,3D,2] bf16 and iir_state [B,D,8] complex64 are updated in place."""
