@@ -21,7 +21,7 @@ ARCH = "gfx950"
 EXPORTS = [
     "evo_abi_version", "evo_embed_bf16", "evo_rmsnorm_bf16", "evo_hyena_seg_state", "evo_hyena_carry_scan", "evo_hyena_carry_add",
     "evo_hyena_apply", "evo_hyena_step", "evo_rope_qk_bf16", "evo_attn_fwd_causal_bf16", "evo_attn_decode_bf16",
-    "evo_linear_small_m_bf16", "evo_gelu_gate_bf16",
+    "evo_linear_small_m_bf16", "evo_linear_mfma_bf16", "evo_gelu_gate_bf16",
     "evo_logprob_entropy",
 ]
 
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     tmp = out.with_suffix(".so.tmp%d" % os.getpid())
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-o", str(tmp)] + os.environ.get("EVO_AMD_HIPCC_FLAGS", "").split() \
+           "-fno-gpu-rdc", "-Wno-inline-asm", "-o", str(tmp)] + os.environ.get("EVO_AMD_HIPCC_FLAGS", "").split() \
         + [str(s) for s in sources()]
     if verbose:
         print(" ".join(cmd))

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR], _c.c_int),
     "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -191,6 +192,26 @@ class HipOps:
         with self._t("gemv"):
             _check(self.lib.evo_linear_small_m_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(res), y.data_ptr(),
                                                     M, N, K, _stream()), "evo_linear_small_m_bf16")
+        return y
+
+    @staticmethod
+    def mfma_linear_ok(x, w):
+        return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
+                and w.is_contiguous() and w.shape[0] % 256 == 0 and x.shape[1] % 64 == 0 and x.shape[0] > 8)
+
+    def linear_mfma(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None,
+                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Hand-written MFMA dense layer (csrc/gemm.hip): x [M,K] @ w[N,K]^T (+ b) (+ residual, in place) -> [M,N]."""
+        self._need(x, torch.bfloat16, "linear_mfma x")
+        self._need(w, torch.bfloat16, "linear_mfma w")
+        M, K = x.shape
+        N = w.shape[0]
+        if residual is not None:
+            self._need(residual, torch.bfloat16, "linear_mfma residual")
+        y = residual if residual is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        with self._t("gemm_mfma"):
+            _check(self.lib.evo_linear_mfma_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(residual), y.data_ptr(),
+                                                 M, N, K, _stream()), "evo_linear_mfma_bf16")
         return y
 
     # ---- kernels -------------------------------------------------------------------------------------

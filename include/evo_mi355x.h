@@ -132,6 +132,15 @@ int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
 int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                             int64_t M, int64_t N, int64_t K, void* stream);
 
+/* ---- dense layer on the MFMA pipe (prefill) --------------------------------------------------------------
+ * replaces the cuBLAS nn.Linear GEMMs of the attention block: Wqkv (with bias) and out_proj (+ residual)
+ *                                                     [REF stripedhyena/model.py:52-59 (MHA projections), :84-92]
+ * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]); all bf16, fp32 accumulate on
+ * v_mfma_f32_32x32x16_bf16, one rounding.  N % 256 == 0, K % 64 == 0, any M >= 1 (ragged last row tile);
+ * `residual` may alias `y`; `x` must not alias `y`.  Returns -1 for an unsupported shape. */
+int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                         int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ---- gated MLP activation ---------------------------------------------------------------------------
  * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]
  * g [M, 2*I] bf16 = [l1 x | l2 x]  ->  a [M, I] bf16 = gelu_erf(g[:, :I]) * g[:, I:]. */

@@ -1,0 +1,77 @@
+"""GPU parity of the hand-written MFMA dense layer (csrc/gemm.hip, evo_linear_mfma_bf16) through the C ABI.
+
+Reference: the same product accumulated in fp32 (fp64 for the tolerance floor) from the bf16 operands, plus bias and
+residual in fp32, rounded once to bf16 -- what nn.Linear (+ residual add) computes in the reference's attention block
+[REF stripedhyena/model.py:52-59], up to summation order.  Tolerance: 1 bf16 ulp of the result magnitude + fp32
+accumulation-order noise.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from evo_amd.ops import default_ops
+    return default_ops()
+
+
+def _ref(x, w, b, r):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if r is not None:
+        y = y + r.double()
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(9, 256, 64), (256, 256, 128), (300, 512, 192), (1000, 768, 4096), (513, 12288, 512),
+                                   (2049, 4096, 4096)])
+@pytest.mark.parametrize("bias,res", [(False, False), (True, False), (False, True), (True, True)])
+def test_linear_mfma_matches_fp64(M, N, K, bias, res):
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if res else None
+    want = _ref(x, w, b, r)
+    got = ops.linear_mfma(x, w, b, r.clone() if res else None)
+    assert got.shape == (M, N) and got.dtype == torch.bfloat16
+    err = (got.double() - want).abs()
+    tol = want.abs() * 2.0 ** -8 + 1e-3          # one bf16 rounding (half-ulp = 2^-9 relative) with margin
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} at {err.argmax().item()}"
+    # and no worse than the library path (GEMM rounded to bf16, then bias / residual added and rounded again)
+    lib = torch.mm(x, w.t()).float()
+    if b is not None:
+        lib = lib + b.float()
+    if r is not None:
+        lib = lib + r.float()
+    lib = lib.to(torch.bfloat16).double()
+    assert err.mean().item() <= (lib - want).abs().mean().item() * 1.05 + 1e-6
+
+
+def test_linear_mfma_residual_in_place_and_untouched_rows():
+    ops = _ops()
+    M, N, K = 700, 512, 256
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") / 16).to(torch.bfloat16)
+    buf = torch.randn(M + 64, N, device="cuda").to(torch.bfloat16)     # rows past M must stay untouched
+    keep = buf.clone()
+    out = ops.linear_mfma(x, w, None, buf[:M])
+    assert out.data_ptr() == buf.data_ptr()
+    assert torch.equal(buf[M:], keep[M:])
+    want = _ref(x, w, None, keep[:M])
+    assert (buf[:M].double() - want).abs().max().item() < 0.05
+
+
+def test_linear_mfma_rejects_unsupported_shapes():
+    ops = _ops()
+    x = torch.zeros(16, 96, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(256, 96, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.linear_mfma(x, w)                                            # K % 64 != 0
+    x = torch.zeros(16, 64, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(100, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.linear_mfma(x, w)                                            # N % 256 != 0
