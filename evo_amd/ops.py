@@ -143,6 +143,7 @@ class HipOps:
         if not torch.cuda.is_available():
             raise EvoLibraryError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.seg_len_override = int(os.environ.get("EVO_AMD_SEG_LEN", "0"))
+        self.attn_gemm_mfma = os.environ.get("EVO_AMD_ATTN_GEMM", "mfma").lower() != "hipblaslt"
         self.timer: Optional[KernelTimer] = None
 
     def _t(self, name):
@@ -159,19 +160,25 @@ class HipOps:
             raise RuntimeError(f"{what}: tensor must be contiguous")
 
     # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
-    def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 8 (decode) takes the weight-streaming kernel."""
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, mfma: bool = False) -> torch.Tensor:
+        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 8 (decode) takes the weight-streaming kernel; `mfma=True`
+        (the attention block's projections) takes the hand-written MFMA kernel of csrc/gemm.hip when the shape allows
+        (EVO_AMD_ATTN_GEMM=hipblaslt routes those to the library too); everything else is hipBLASLt."""
         if self._use_small_m(x, w):
             return self._linear_small_m(x, w, b, None)
+        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w):
+            return self.linear_mfma(x, w, b)
         with self._t("gemm"):
             if b is not None:
                 return torch.addmm(b, x, w.t())
             return torch.mm(x, w.t())
 
-    def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor, mfma: bool = False) -> torch.Tensor:
         """res += x @ w^T (fp32 accumulate, one rounding), in place."""
         if self._use_small_m(x, w) and res.is_contiguous():
             return self._linear_small_m(x, w, None, res)
+        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w) and res.is_contiguous():
+            return self.linear_mfma(x, w, None, res)
         with self._t("gemm"):
             return res.addmm_(x, w.t())
 

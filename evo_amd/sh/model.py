@@ -316,7 +316,7 @@ class StripedHyena(nn.Module):
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         mha = blk.inner_mha_cls
         n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
-        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, T, 3, H, hd)
+        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
         off = int(cache.seqlen_offset) if cache is not None else 0
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]
@@ -341,7 +341,7 @@ class StripedHyena(nn.Module):
                 a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
             else:
                 a = ops.attention(q, k, v, off).view(B * T, D)
-        ops.linear_residual_(x2d, a, mha.out_proj.weight)
+        ops.linear_residual_(x2d, a, mha.out_proj.weight, mfma=True)
         self._mlp_residual_(blk, x2d, mha.out_proj.bias)
 
     # ------------------------------------------------------------------ forward

@@ -127,14 +127,14 @@ class SequenceParallelScorer:
         D, H, hd = m.hidden_size, m.num_heads, m.head_dim
         mha = blk.inner_mha_cls
         n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
-        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias).view(B, Tloc, 3, H, hd)
+        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, Tloc, 3, H, hd)
         cos, sin = m._rotary(t0, Tloc, x2d.device)
         ops.rope_(qkv, cos, sin)
         if self.attn_mode != "allgather" and H % self.world == 0 and hasattr(self.comm, "all_to_all"):
             a = self._attn_ulysses(qkv, B, Tloc, Tl, T)
         else:
             a = self._attn_allgather(qkv, B, Tloc, Tl, t0)
-        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight)
+        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight, mfma=True)
         m._mlp_residual_(blk, x2d, mha.out_proj.bias)
 
     def _attn_ulysses(self, qkv, B, Tloc, Tl, T):

@@ -17,13 +17,13 @@ class OracleOps:
     def _o(self, t):
         return t.to(self.act)
 
-    def linear(self, x, w, b=None):
+    def linear(self, x, w, b=None, mfma=False):
         y = x.double() @ w.double().t()
         if b is not None:
             y = y + b.double()
         return self._o(y)
 
-    def linear_residual_(self, res, x, w):
+    def linear_residual_(self, res, x, w, mfma=False):
         res.copy_(self._o(res.double() + x.double() @ w.double().t()))
         return res
 
