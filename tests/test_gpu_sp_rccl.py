@@ -1,0 +1,53 @@
+"""GPU (-m gpu): the sequence-parallel scorer through the REAL torch.distributed communicator on the "nccl" (= RCCL)
+backend.  The test box has one GPU, so the group has world size 1: the collectives are degenerate, but process-group
+creation, every all_gather_into_tensor / all_to_all_single call, their dtypes, shapes and stream ordering are the ones
+the driver's N = 2, 4, 8 runs take.  The R > 1 arithmetic is covered by tests/test_sp_gloo.py (gloo, world 2 and 3)
+and by the virtual-rank test in tests/test_gpu_model.py (HIP kernels, world 2 and 4).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from test_gpu_model import DEV, SMALL, acgt, build
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("attn_mode", ["auto", "allgather"])
+def test_sequence_parallel_on_rccl_world1(attn_mode):
+    from evo_amd.sp import SequenceParallelScorer
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        cfgd = dict(SMALL, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+        cfg, sd, m = build(cfgd)
+        ids = acgt(2, 600).to(DEV)
+        with torch.inference_mode():
+            full = m(ids)[0].float()
+            sp = SequenceParallelScorer(m, 0, 1)
+            sp.attn_mode = attn_mode
+            lg = sp.forward_local(ids).float()
+            lp = sp.gather_logprobs(sp.score_logprobs(ids), ids.shape[1])
+        assert dist.get_backend() == "nccl"
+        assert lg.shape == full.shape
+        # same kernels on the same data; the SP path adds an exactly-zero carry and a 1-way exchange
+        assert ((lg - full).norm() / full.norm()).item() < 2e-3
+        from evo_amd.scoring import logits_to_logprobs
+        want = logits_to_logprobs(full.cpu(), ids.cpu(), trim_bos=True)
+        assert lp.shape == want.shape
+        assert (lp.cpu().double() - want.double()).abs().mean() < 5e-2
+    finally:
+        dist.destroy_process_group()
