@@ -36,7 +36,7 @@ struct AttnArgs {
     float scale_log2;      // softmax_scale * log2(e)
     int n_qblocks;
     // decode (split-K) mode only
-    const int64_t* dyn_pos;   // device scalar: position of the (single) query; overrides Tk / q_pos0 when non-null
+    const int64_t* dyn_pos;   // device int64 [B]: position of each row's (single) query; overrides Tk / q_pos0 when non-null
     float* part_o;            // [B, H, n_splits, 128] unnormalised partial outputs
     float* part_ml;           // [B, H, n_splits, 2]   running max (log2 domain) and denominator
     int n_splits;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
     const int l31 = lane & 31;
 
     int64_t Tk_ = a.Tk, q_pos0_ = a.q_pos0;
-    if (DECODE && a.dyn_pos) { q_pos0_ = a.dyn_pos[0]; Tk_ = q_pos0_ + a.Tq; }
+    if (DECODE && a.dyn_pos) { q_pos0_ = a.dyn_pos[blockIdx.z]; Tk_ = q_pos0_ + a.Tq; }
     int qb = 0, head = blockIdx.y, bat = blockIdx.z;
     if (!DECODE) attn_block_map(a, qb, head, bat);
     const int64_t q0 = (int64_t)qb * QB;

@@ -369,8 +369,13 @@ class HipOps:
     def attention_decode(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                          pos: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
         """One query per sequence against the KV cache: q [B,1,H,128]; k/v [B,Tk,H,128] views.  With `pos`
-        (device int64 scalar) the query sits at pos and sees keys [0,pos]; Tk is then just the capacity."""
+        (device int64 [B], or [1] = same for every row) row b's query sits at pos[b] and sees keys [0,pos[b]];
+        Tk is then just the capacity."""
         B, Tq, H, hd = q.shape
+        if pos is not None:
+            if pos.dtype != torch.int64 or not pos.is_cuda or pos.numel() not in (1, B):
+                raise RuntimeError("attention_decode pos: need a device int64 tensor with 1 or B entries")
+            pos = (pos.reshape(1).expand(B) if pos.numel() == 1 and B > 1 else pos.reshape(-1)).contiguous()
         if Tq != 1 or hd != 128:
             raise RuntimeError("attention_decode: expects [B,1,H,128] queries")
         for t, nm in ((q, "q"), (k, "k"), (v, "v")):

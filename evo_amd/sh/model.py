@@ -242,8 +242,15 @@ class StripedHyena(nn.Module):
         self._rot_cache[key] = (cos, sin)
         return cos, sin
 
+    def _row_index(self, B: int, device) -> torch.Tensor:
+        hit = getattr(self, "_rows", None)
+        if hit is None or hit.numel() < B or hit.device != torch.device(device):
+            hit = self._rows = torch.arange(max(B, 8), dtype=torch.int64, device=device)
+        return hit[:B]
+
     def _rotary_dyn(self, pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Same table for ONE position held in device memory (int64 [1]) -- no host read, graph-capturable."""
+        """Same table for positions held in device memory (int64 [n]: one per decode stream) -- no host read,
+        graph-capturable.  Returns cos, sin [n, hd/2]."""
         hd = self.head_dim
         dev = pos.device
         inv = getattr(self, "_inv_freq_dev", None)
@@ -321,11 +328,13 @@ class StripedHyena(nn.Module):
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]
         if pos is not None and T == 1:
-            # position-independent decode step (hipGraph replay): the position lives in device memory
+            # position-independent decode step (hipGraph replay, continuous batching): one position PER ROW, in
+            # device memory.  The rotary kernel indexes its table by token, so the B rows are presented as one
+            # sequence of B tokens with the per-row table.
             cos, sin = self._rotary_dyn(pos)
-            ops.rope_(qkv, cos, sin)
+            ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin)
             kv = cache.key_value_memory_dict[i][:B]
-            kv.index_copy_(1, pos, qkv[:, :, 1:3])
+            kv[self._row_index(B, x2d.device), pos] = qkv[:, 0, 1:3]
             a = ops.attention_decode(q, kv[:, :, 0], kv[:, :, 1], pos=pos).view(B, D)
         else:
             cos, sin = self._rotary(off, T, x2d.device)
@@ -420,12 +429,13 @@ class StripedHyena(nn.Module):
                     return None
                 dev = self.device
                 st = {"key": key, "ids": torch.zeros(B, 1, dtype=torch.int64, device=dev),
-                      "pos": torch.zeros(1, dtype=torch.int64, device=dev),
+                      "pos": torch.zeros(B, dtype=torch.int64, device=dev),
                       "kv_ptrs": {i: mha.key_value_memory_dict[i].data_ptr() for i in self.attn_layer_idxs},
                       "st_ptrs": {i: ipd["hyena"].state_dict[i].data_ptr() for i in self.hyena_layer_idxs}}
                 st["ids"].copy_(x)
                 st["pos"].fill_(off)
                 mha.pos_tensor = st["pos"]
+                self._row_index(B, dev)             # (allocated outside the capture)
                 g = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(g):

@@ -113,9 +113,10 @@ int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* 
 /* decode form (one query per sequence, Tq = 1): split-K over the key range ("flash-decoding") + combine.
  * replaces flash_attn_with_kvcache                           [REF evo/generation.py:109-110,138-155]
  *   q [B, 1, H, 128] (q_sb, q_sh strides), k/v views of the KV cache [B, cap, H, 128];
- *   dyn_pos: NULL -> the query sits at position Tk-1 and sees keys [0, Tk);  non-NULL -> a device int64 scalar
- *            p: the query sits at p and sees keys [0, p] (Tk is then only the cache capacity bound) -- the launch
- *            no longer depends on the position, so a captured hipGraph can be replayed for every token;
+ *   dyn_pos: NULL -> the query sits at position Tk-1 and sees keys [0, Tk);  non-NULL -> device int64 [B]:
+ *            row b's query sits at p_b = dyn_pos[b] and sees keys [0, p_b] (Tk is then only the cache capacity
+ *            bound).  The launch no longer depends on the positions, so a captured hipGraph can be replayed for
+ *            every token, and rows may be at DIFFERENT positions (continuous batching of decode streams);
  *   part_o [B, H, n_splits, 128] f32 and part_ml [B, H, n_splits, 2] f32: caller-owned workspace. */
 int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
                          int64_t B, int64_t H, int64_t Tk,

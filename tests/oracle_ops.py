@@ -77,5 +77,11 @@ class OracleOps:
         return self._o(y)
 
     def attention_decode(self, q, k, v, pos=None, n_splits=None):
-        Tk = k.shape[1] if pos is None else int(pos.item()) + 1
-        return self._o(R.op_attention(q, k[:, :Tk], v[:, :Tk], Tk - 1))
+        if pos is None or pos.numel() == 1:
+            Tk = k.shape[1] if pos is None else int(pos.item()) + 1
+            return self._o(R.op_attention(q, k[:, :Tk], v[:, :Tk], Tk - 1))
+        rows = []                                  # one position per row (continuous batching)
+        for b in range(q.shape[0]):
+            Tk = int(pos[b].item()) + 1
+            rows.append(R.op_attention(q[b:b + 1], k[b:b + 1, :Tk], v[b:b + 1, :Tk], Tk - 1))
+        return self._o(torch.cat(rows, 0))

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--model", default="evo-1-131k-base")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pool", type=int, default=0, help="continuous batching: number of decode slots (0 = off)")
+    ap.add_argument("--jobs", type=int, default=16, help="pool mode: number of prompts (lengths vary 0.5x..1x --prompt)")
     args = ap.parse_args()
     from bench import build_model
     from evo_amd.generation import Generator
@@ -30,6 +32,24 @@ def main():
     tok = CharLevelTokenizer(512)
     rng = np.random.default_rng(7)
     ids = torch.from_numpy(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(args.batch, args.prompt)).astype(np.int64)).to(dev)
+    if args.pool:
+        from evo_amd.pool import DecodePool
+        lens = [int(args.prompt * (0.5 + 0.5 * (j % 5) / 4)) for j in range(args.jobs)]
+        prompts = ["".join(rng.choice(list("ACGT"), size=n)) for n in lens]
+        pool = DecodePool(model, tok, n_slots=args.pool, top_k=4, top_p=1.0, temperature=0.7, device=dev,
+                          use_graph=not args.no_graph)
+        pool.generate(prompts[:2], n_tokens=4)                 # warm-up (allocations, graph capture)
+        for rep in range(2):
+            pool.stats = {"steps": 0, "prefills": 0, "tokens": 0}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            seqs, scores, _ = pool.generate(prompts, n_tokens=args.new)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"[pool slots={args.pool} graph={not args.no_graph} rep{rep}] {args.jobs} prompts of {min(lens)}..{max(lens)} nt, "
+                  f"{args.new} new tokens each: {dt * 1e3:.0f} ms total, {args.jobs * args.new / dt:.0f} tok/s aggregate "
+                  f"({pool.stats['steps']} steps, {dt / max(1, pool.stats['steps']) * 1e3:.2f} ms/step incl. prefills)")
+        return
     g = Generator(model, tok, top_k=1, top_p=1.0, temperature=1.0)
 
     def run(n):
