@@ -294,7 +294,12 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
     a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)((M + GBM - 1) / GBM);
-    { const char* e = getenv("EVO_GEMM_GROUP_M"); a.group_m = e ? atoi(e) : 4; if (a.group_m < 1) a.group_m = 1; }
+    static const int group_m = [] {                              // raster width: 4 measured best (profiles/r01_gemm_notes.txt)
+        const char* e = getenv("EVO_GEMM_GROUP_M");
+        const int g = e ? atoi(e) : 4;
+        return g < 1 ? 1 : g;
+    }();
+    a.group_m = group_m;
     const int64_t tiles = ((M + GBM - 1) / GBM) * a.tiles_n;
     if (tiles > 0x7fffffff) return -1;
     a.n_tiles = (int)tiles;
