@@ -66,6 +66,23 @@ def main():
             print(f"[{tag}] attn B={Bq} T={T}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
             del qkv
 
+    if args.only in ("", "elem"):
+        M = 8 * 8193
+        gg = rn(M, 2 * 11008).bfloat16()
+        x = rn(M, D).bfloat16()
+        sc = rn(D).bfloat16()
+        bi = rn(D).bfloat16()
+        for _ in range(2):
+            ops.gelu_gate(gg); ops.rmsnorm(x, None, sc, 1e-6); ops.rmsnorm(x, bi, sc, 1e-6)
+        ops.timer = KernelTimer()
+        for _ in range(args.reps):
+            ops.gelu_gate(gg); ops.rmsnorm(x, None, sc, 1e-6); ops.rmsnorm(x, bi, sc, 1e-6)
+        torch.cuda.synchronize()
+        s = ops.timer.summary()
+        ops.timer = None
+        byt = {"gelu_gate": M * 11008 * 6, "rmsnorm": M * D * 4, "rmsnorm_bias": M * D * 6}
+        print(f"[{tag}] elementwise M={M}: " + " ".join(f"{k}={v[1]:.3f}ms ({byt[k] / v[1] / 1e6:.0f} GB/s)" for k, v in s.items()))
+
 
 if __name__ == "__main__":
     main()
