@@ -1,4 +1,9 @@
-// Skinny dense layer for decoding: y[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) (+ residual[M,N]), M <= 8.
+// Skinny dense layer for decoding: y[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) (+ residual[M,N]), M <= 16.
+//
+// Two kernels.  gemv_kernel (M <= 4, or any K % 8 == 0 shape): dot2 on the VALU, below.  skinny_mfma_kernel
+// (5 <= M <= 16, K % 32 == 0): the batch rows become the N side of v_mfma_f32_16x16x32_bf16 -- with 5+ rows the VALU
+// form spends more on re-reading x from L2 (M loads per R weight loads) than on the weights; here one 1-KiB x
+// fragment meets one 1-KiB weight fragment per MFMA and the math is free.
 //
 // At batch 1-8 a decode step streams all 12.9 GB of weights once and is bound by HBM, not by MFMA: through
 // hipBLASLt's tile GEMM it ran at ~2.5 TB/s (5.2 ms/token).  This kernel is the weight-streaming form: one wave
@@ -90,6 +95,62 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     }
 }
 
+// ---- 5 <= M <= 16: MFMA form.  Workgroup = 8 waves = 16 output rows; wave w streams its eighth of K:
+//   A operand = W rows   (lane: row n = lane & 15, k-block = lane >> 4 -> 16 B = 8 bf16, non-temporal, straight to VGPRs)
+//   B operand = x rows   (lane: row m = lane & 15, same k-block; rows >= M re-read row M-1 and are never stored)
+//   D[n][m]: lane holds n = 4 (lane >> 4) + r, m = lane & 15.
+// The eight partial tiles meet in LDS; wave 0 adds bias / residual and stores (one rounding).
+typedef float gv_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                          const uint16_t* __restrict__ bias, const uint16_t* res,
+                                                          uint16_t* y, int M, int N, int nvec) {   // res may alias y
+    __shared__ gv_f32x4 part[8][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kb = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
+    const int mrow = r16 < M ? r16 : M - 1;
+    const int nsteps = nvec >> 2;                                // 32 k per MFMA = 4 vectors of 8
+    const int s0 = (int)((int64_t)nsteps * wave / 8), s1 = (int)((int64_t)nsteps * (wave + 1) / 8);
+    const uint4* wp = w + (int64_t)nrow * nvec + kb;
+    const uint4* xp = x + (int64_t)mrow * nvec + kb;
+    gv_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+        uint4 wf[8], xf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wf[u] = ld_stream(wp + 4 * (s + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xf[u] = xp[4 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[u]), __builtin_bit_cast(bf16x8_t, xf[u]),
+                                                          acc, 0, 0, 0);
+    }
+    for (; s < s1; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ld_stream(wp + 4 * s)),
+                                                      __builtin_bit_cast(bf16x8_t, xp[4 * s]), acc, 0, 0, 0);
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) acc += part[q][lane];
+        const int m = r16;
+        if (m < M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * kb + r;
+                if (n < N) {
+                    float o = acc[r] + (bias ? bf_to_f(bias[n]) : 0.f);
+                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
+                    y[(int64_t)m * N + n] = f_to_bf(o);
+                }
+            }
+        }
+    }
+}
+
 template <int M>
 static void gemv_launch(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t N, int64_t K,
                         hipStream_t s) {
@@ -112,8 +173,15 @@ static void gemv_launch(const void* x, const void* w, const void* bias, const vo
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                                        int64_t M, int64_t N, int64_t K, void* stream) {
-    if (M < 1 || M > 8 || N <= 0 || K <= 0 || K % 8 != 0) return -1;
+    if (M < 1 || M > 16 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
+    if (M > 8 && K % 32 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
+    if (M >= 5 && K % 32 == 0) {
+        hipLaunchKernelGGL(skinny_mfma_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, (const uint4*)x,
+                           (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N,
+                           (int)(K / 8));
+        return evo_launch_status();
+    }
     switch (M) {
         case 1: gemv_launch<1>(x, w, bias, residual, y, N, K, s); break;
         case 2: gemv_launch<2>(x, w, bias, residual, y, N, K, s); break;

@@ -184,13 +184,15 @@ class HipOps:
 
     @staticmethod
     def _use_small_m(x, w):
-        """Measured crossover (tools/bench_gemv.py): the streaming kernel beats hipBLASLt for M <= 4 on every
-        layer shape, and for M <= 8 on the N <= 4096 layers (out / l3 / unembed)."""
-        M = x.shape[0]
-        if not (1 <= M <= 8 and (M <= 4 or w.shape[0] <= 4096)):
+        """The weight-streaming kernels (csrc/gemv.hip) serve every decode-sized batch: dot2 form up to M = 4 (and
+        for K % 32 != 0 up to M = 8), MFMA form for 5 <= M <= 16 (tools/bench_gemv.py for the crossovers)."""
+        M, K = x.shape
+        if not (1 <= M <= 16):
+            return False
+        if K % 32 != 0 and not (M <= 4 or (M <= 8 and w.shape[0] <= 4096)):
             return False
         return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
-                and w.is_contiguous() and x.shape[1] % 8 == 0)
+                and w.is_contiguous() and K % 8 == 0)
 
     def _linear_small_m(self, x, w, b, res):
         M, K = x.shape

@@ -128,8 +128,9 @@ int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
 
 /* ---- skinny dense layer (decode) ----------------------------------------------------------------------
  * replaces cuBLAS GEMV-shaped nn.Linear calls of the single-token forward   [REF evo/generation.py:151-155]
- * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 8, K % 8 == 0, all bf16,
- * fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) form; `residual` may alias `y`. */
+ * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 16, K % 8 == 0 (K % 32 == 0 for
+ * M > 8), all bf16, fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) forms: dot2 on the VALU up to
+ * M = 4, v_mfma_f32_16x16x32_bf16 with the batch rows on the MFMA's N side from M = 5; `residual` may alias `y`. */
 int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                             int64_t M, int64_t N, int64_t K, void* stream);
 

@@ -27,10 +27,10 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-for M in (1, 2, 4, 8):
+for M in (1, 2, 4, 5, 8, 12, 16):
     tot_mine = tot_torch = 0.0
     line = []
-    for name, N, K in (("proj", 12288, 4096), ("out", 4096, 4096), ("l1l2", 21856, 4096), ("l3", 4096, 10928)):
+    for name, N, K in (("proj", 12288, 4096), ("out", 4096, 4096), ("l1l2", 22016, 4096), ("l3", 4096, 11008)):
         # rotate over several weight copies so the 256 MB Infinity Cache cannot hold the operand
         ws = [(torch.randn(N, K, generator=g, device=dev) * 0.02).bfloat16() for _ in range(6)]
         x = torch.randn(M, K, generator=g, device=dev).bfloat16()
