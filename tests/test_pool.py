@@ -68,3 +68,26 @@ def test_sample_many_stochastic_is_well_formed(model_and_reference):
     assert prompts == [PROMPTS[0]] * 2 + [PROMPTS[1]] * 2 + [PROMPTS[2]] * 2
     assert len(seqs) == len(scores) == 6 and all(len(s) == 5 for s in seqs)
     assert all(np.isfinite(scores)) and all(s <= 0 for s in scores)
+
+
+def test_sample_many_cli_writes_reference_csv(tmp_path, monkeypatch, model_and_reference):
+    """scripts/sample_many.py end to end (FASTA in, CSV with the reference's columns out) on the oracle backend."""
+    import csv
+    import types
+
+    import evo_amd
+    from scripts import sample_many as cli
+    m, seqs, scores = model_and_reference
+    monkeypatch.setattr(evo_amd, "Evo", lambda name, device=None, weights=None: types.SimpleNamespace(model=m, tokenizer=TOK))
+    fa = tmp_path / "prompts.fa"
+    fa.write_text(">p0 first\n" + PROMPTS[0] + "\n>p1\n" + PROMPTS[1] + "\n>blank\n\n")
+    out = tmp_path / "out.csv"
+    rows = cli.main(["--prompts", str(fa), "--output-csv", str(out), "--n-tokens", "7", "--n-sample-per-prompt", "2",
+                     "--top-k", "1", "--temperature", "0.0", "--n-slots", "3", "--device", "cpu"])
+    got = list(csv.reader(open(out)))
+    assert got[0] == ["UUID", "Prompt", "Generated Sequence", "Score"]
+    assert len(got) == 1 + 4 and len(rows) == 4
+    assert [r[1] for r in got[1:]] == [PROMPTS[0]] * 2 + [PROMPTS[1]] * 2
+    assert [r[2] for r in got[1:]] == [seqs[0]] * 2 + [seqs[1]] * 2
+    assert all(len(r[0]) == 32 for r in got[1:]) and len({r[0] for r in got[1:]}) == 4
+    np.testing.assert_allclose([float(r[3]) for r in got[1:]], [scores[0]] * 2 + [scores[1]] * 2, rtol=1e-6)
