@@ -160,12 +160,32 @@ class HipOps:
             raise RuntimeError(f"{what}: tensor must be contiguous")
 
     # ---- dense layers (hipBLASLt via torch) --------------------------------------------------------
+    @staticmethod
+    def _tail_rows(x, w) -> int:
+        """Rows to peel off a big dense layer: the BOS token makes M = B * (nt + 1) = 256 k + (1..16), and that last
+        sliver costs a whole extra row of 256-row tiles (measured on hipBLASLt: +0.7 ... +4.7 % per GEMM at
+        M = 65,544, +0.5 ... +3.7 % at 131,073).  Dense layers are row-independent, so the sliver goes through the
+        weight-streaming kernel instead."""
+        M, K = x.shape
+        r = M % 256
+        if M >= 4096 and 1 <= r <= 16 and K % 32 == 0 and x.is_cuda and x.dtype == torch.bfloat16 \
+                and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous():
+            return r
+        return 0
+
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, mfma: bool = False) -> torch.Tensor:
-        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 8 (decode) takes the weight-streaming kernel; `mfma=True`
+        """x [M,K] @ w[N,K]^T (+ b) -> [M,N] bf16.  M <= 16 (decode) takes the weight-streaming kernels; `mfma=True`
         (the attention block's projections) takes the hand-written MFMA kernel of csrc/gemm.hip when the shape allows
         (EVO_AMD_ATTN_GEMM=hipblaslt routes those to the library too); everything else is hipBLASLt."""
         if self._use_small_m(x, w):
             return self._linear_small_m(x, w, b, None)
+        r = self._tail_rows(x, w)
+        if r:
+            M = x.shape[0]
+            y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device)
+            self._linear_into(y[: M - r], x[: M - r], w, b, mfma)
+            self._linear_small_m(x[M - r:], w, b, None, out=y[M - r:])
+            return y
         if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w):
             return self.linear_mfma(x, w, b)
         with self._t("gemm"):
@@ -173,10 +193,28 @@ class HipOps:
                 return torch.addmm(b, x, w.t())
             return torch.mm(x, w.t())
 
+    def _linear_into(self, y, x, w, b, mfma):
+        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w):
+            with self._t("gemm_mfma"):
+                _check(self.lib.evo_linear_mfma_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), None, y.data_ptr(),
+                                                     x.shape[0], w.shape[0], x.shape[1], _stream()), "evo_linear_mfma_bf16")
+            return
+        with self._t("gemm"):
+            if b is not None:
+                torch.addmm(b, x, w.t(), out=y)
+            else:
+                torch.mm(x, w.t(), out=y)
+
     def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor, mfma: bool = False) -> torch.Tensor:
         """res += x @ w^T (fp32 accumulate, one rounding), in place."""
         if self._use_small_m(x, w) and res.is_contiguous():
             return self._linear_small_m(x, w, None, res)
+        r = self._tail_rows(x, w) if res.is_contiguous() else 0
+        if r:
+            M = x.shape[0]
+            self.linear_residual_(res[: M - r], x[: M - r], w, mfma)
+            self._linear_small_m(x[M - r:], w, None, res[M - r:])
+            return res
         if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w) and res.is_contiguous():
             return self.linear_mfma(x, w, None, res)
         with self._t("gemm"):
@@ -194,10 +232,10 @@ class HipOps:
         return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
                 and w.is_contiguous() and K % 8 == 0)
 
-    def _linear_small_m(self, x, w, b, res):
+    def _linear_small_m(self, x, w, b, res, out=None):
         M, K = x.shape
         N = w.shape[0]
-        y = res if res is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        y = res if res is not None else (out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
         with self._t("gemv"):
             _check(self.lib.evo_linear_small_m_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(res), y.data_ptr(),
                                                     M, N, K, _stream()), "evo_linear_small_m_bf16")
