@@ -75,3 +75,34 @@ def test_linear_mfma_rejects_unsupported_shapes():
     w = torch.zeros(100, 64, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.linear_mfma(x, w)                                            # N % 256 != 0
+
+
+@pytest.mark.parametrize("M", [4096 + 8, 8192 + 1, 4096 + 16, 4096 + 17, 4096])
+@pytest.mark.parametrize("mode", ["plain", "bias", "residual", "mfma_bias", "mfma_residual"])
+def test_linear_peels_the_row_sliver(M, mode):
+    """HipOps.linear / linear_residual_ send the M % 256 (<= 16) trailing rows through the weight-streaming kernel and
+    the rest through the tile GEMM; the result must not show the seam."""
+    ops = _ops()
+    N, K = 512, 256
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    mfma = mode.startswith("mfma")
+    if mode.endswith("residual"):
+        got = ops.linear_residual_(r.clone(), x, w, mfma=mfma)
+        want = _ref(x, w, None, r)
+    elif mode.endswith("bias"):
+        got = ops.linear(x, w, b, mfma=mfma)
+        want = _ref(x, w, b, None)
+    else:
+        got = ops.linear(x, w, None)
+        want = _ref(x, w, None, None)
+    err = (got.double() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -8 + 2e-3).all()), f"max err {err.max().item():.3e} at row {err.argmax().item() // N}"
+    assert HipOpsTail(ops, x, w) == (M % 256 if 1 <= M % 256 <= 16 else 0)
+
+
+def HipOpsTail(ops, x, w):
+    return ops._tail_rows(x, w)
