@@ -5,7 +5,8 @@
     rocprofv3 --pmc FETCH_SIZE  -d gpurun_out/pmc_fetch -o ops -- python tools/profile_ops.py --reps 2
     rocprofv3 --pmc WRITE_SIZE  -d gpurun_out/pmc_write -o ops -- python tools/profile_ops.py --reps 2
 Random (never zero) inputs; shapes: Hyena / RMSNorm / GELU-gate at B=1, T=131,073, D=4096 (BASELINE configs[2])
-and at B=8, T=8,193 (configs[1]); attention at B=1, H=32, T=16,385 (one 131k/8 shard length) unless --attn-T.
+and at B=8, T=8,193 (configs[1]); attention at B=1, H=32, T=16,385 (one 131k/8 shard length) unless --attn-T; the
+MFMA dense layer at M = 65,536 (Wqkv, out_proj) and the weight-streaming dense layer at M = 1, 8, 16.
 """
 import argparse
 import math
@@ -57,6 +58,18 @@ def main():
     for _ in range(max(1, args.reps // 2)):
         ops.rope_(qkv, cos, sin)
         ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+    # dense layers written here: the MFMA tile kernel at the Wqkv / out_proj shapes, the weight-streaming forms at M = 1, 8, 16
+    M = 8 * 8192
+    xa = rn(M, D).bfloat16()
+    wq = rn(3 * D, D, std=1 / 64).bfloat16()
+    wo = rn(D, D, std=1 / 64).bfloat16()
+    bq = rn(3 * D, std=0.02).bfloat16()
+    r = rn(M, D).bfloat16()
+    for _ in range(max(1, args.reps // 2)):
+        ops.linear_mfma(xa, wq, bq)
+        ops.linear_mfma(xa, wo, None, r)
+        for m in (1, 8, 16):
+            ops._linear_small_m(xa[:m], wq, bq, None)
     torch.cuda.synchronize()
     print("profile_ops done")
 
