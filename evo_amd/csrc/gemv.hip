@@ -31,14 +31,18 @@ __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-template <int M, int R>
+// SPLIT: the four waves of a workgroup share the SAME R rows and each takes every fourth 64-vector slice of K (the
+// partial sums meet in LDS).  Used for the narrow layers (N <= 4096: out_filter_dense, out_proj, l3), where one wave
+// per R rows leaves the chip with too few loads in flight: 3.3 -> see tools/bench_gemv.py.
+template <int M, int R, bool SPLIT>
 __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                    const uint16_t* __restrict__ bias, const uint16_t* res,
                                                    uint16_t* y, int N, int nvec) {   // res may alias y
+    __shared__ float part[SPLIT ? 4 * R * M : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * R;
-    if (n0 >= N) return;
+    const int64_t n0 = SPLIT ? (int64_t)blockIdx.x * R : ((int64_t)blockIdx.x * 4 + wave) * R;
+    if (n0 >= N) return;                                     // (workgroup-uniform when SPLIT)
     const uint4* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -51,19 +55,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 
-    int v = lane;
-    for (; v + 64 < nvec; v += 128) {                        // two k-slices per trip: 2R weight loads in flight
+    constexpr int ST = SPLIT ? 256 : 64;                     // slice stride of this wave
+    int v = SPLIT ? wave * 64 + lane : lane;
+    for (; v + ST < nvec; v += 2 * ST) {                     // two k-slices per trip: 2R weight loads in flight
         uint4 w0[R], w1[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+        for (int r = 0; r < R; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + ST); }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const uint4 x0 = x[(int64_t)m * nvec + v], x1 = x[(int64_t)m * nvec + v + 64];
+            const uint4 x0 = x[(int64_t)m * nvec + v], x1 = x[(int64_t)m * nvec + v + ST];
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
         }
     }
-    for (; v < nvec; v += 64) {
+    for (; v < nvec; v += ST) {
         uint4 w0[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) w0[r] = ld_stream(wrow[r] + v);
@@ -78,6 +83,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (SPLIT) {
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < M; ++m) part[(wave * R + r) * M + m] = acc[r][m];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                acc[r][m] = part[r * M + m] + part[(R + r) * M + m] + part[(2 * R + r) * M + m] + part[(3 * R + r) * M + m];
+    }
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -167,8 +187,12 @@ static void gemv_launch(const void* x, const void* w, const void* bias, const vo
 #endif
     constexpr int R = M <= 2 ? GEMV_R_A : (M <= 4 ? GEMV_R_B : GEMV_R_C);
     const int64_t waves = (N + R - 1) / R;
-    hipLaunchKernelGGL((gemv_kernel<M, R>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)x,
-                       (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));
+    if (N <= 4096 && K >= 2048)
+        hipLaunchKernelGGL((gemv_kernel<M, R, true>), dim3((unsigned)waves), dim3(256), 0, s, (const uint4*)x,
+                           (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));
+    else
+        hipLaunchKernelGGL((gemv_kernel<M, R, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)x,
+                           (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));
 }
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
