@@ -115,6 +115,65 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     }
 }
 
+// ---- gated MLP input, decode form: a[m][n] = gelu(x_m . W1_n) * (x_m . W2_n) with W12 = [W1; W2] ([2I, K]).  Same
+// streaming loop as gemv_kernel; a wave owns 2 output columns = rows (n, n+1) of W1 and (I+n, I+n+1) of W2, rounds both
+// dot products to bf16 (what the unfused GEMM stores) and applies the gate -- one launch instead of two per block.
+template <int M>
+__global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                        uint16_t* __restrict__ a, int I, int nvec) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    if (n0 >= I) return;
+    const uint4* wrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int64_t n = n0 + (r & 1) < I ? n0 + (r & 1) : I - 1;
+        wrow[r] = w + ((r >> 1) * (int64_t)I + n) * nvec;
+    }
+    float acc[4][M];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+    int v = lane;
+    for (; v + 64 < nvec; v += 128) {
+        uint4 w0[4], w1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = x[(int64_t)m * nvec + v], x1 = x[(int64_t)m * nvec + v + 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+        }
+    }
+    for (; v < nvec; v += 64) {
+        uint4 w0[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w0[r] = ld_stream(wrow[r] + v);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = x[(int64_t)m * nvec + v];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const f32x2_t u = {round_bf(acc[0][m]), round_bf(acc[1][m])}, g = {round_bf(acc[2][m]), round_bf(acc[3][m])};
+            const f32x2_t o = gelu_gate2(u, g);
+            if (n0 + 1 < I) *(uint32_t*)(a + (int64_t)m * I + n0) = pack_bf2(o[0], o[1]);
+            else a[(int64_t)m * I + n0] = f_to_bf(o[0]);
+        }
+    }
+}
+
 // ---- 5 <= M <= 16: MFMA form.  Workgroup = 8 waves = 16 output rows; wave w streams its eighth of K:
 //   A operand = W rows   (lane: row n = lane & 15, k-block = lane >> 4 -> 16 B = 8 bf16, non-temporal, straight to VGPRs)
 //   B operand = x rows   (lane: row m = lane & 15, same k-block; rows >= M re-read row M-1 and are never stored)
@@ -193,6 +252,20 @@ static void gemv_launch(const void* x, const void* w, const void* bias, const vo
     else
         hipLaunchKernelGGL((gemv_kernel<M, R, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)x,
                            (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));
+}
+
+extern "C" int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
+                                         void* stream) {
+    if (M < 1 || M > 4 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
+    switch (M) {
+        case 1: hipLaunchKernelGGL(gemv_gate_kernel<1>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
+        case 2: hipLaunchKernelGGL(gemv_gate_kernel<2>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
+        case 3: hipLaunchKernelGGL(gemv_gate_kernel<3>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
+        default: hipLaunchKernelGGL(gemv_gate_kernel<4>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
+    }
+    return evo_launch_status();
 }
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,

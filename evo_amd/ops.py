@@ -35,6 +35,7 @@ _SIGNATURES = {
     "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -434,6 +435,20 @@ class HipOps:
                 part_o.data_ptr(), part_ml.data_ptr(), n_splits, 1.0 / math.sqrt(hd), _stream()),
                 "evo_attn_decode_bf16")
         return o
+
+    def mlp_gate(self, x: torch.Tensor, w12: torch.Tensor) -> torch.Tensor:
+        """a [M, I] = gelu(x @ W1^T) * (x @ W2^T), w12 = [W1; W2] ([2I, K]).  Decode-sized batches (M <= 4) take ONE
+        weight-streaming launch; everything else is the dense layer followed by the gate kernel."""
+        M, K = x.shape
+        I = w12.shape[0] // 2
+        if (1 <= M <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and w12.dtype == torch.bfloat16 and x.is_contiguous()
+                and w12.is_contiguous() and K % 8 == 0 and I % 2 == 0):
+            a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+            with self._t("gemv_gate"):
+                _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), w12.data_ptr(), a.data_ptr(), M, I, K, _stream()),
+                       "evo_mlp_gate_small_m_bf16")
+            return a
+        return self.gelu_gate(self.linear(x, w12, None))
 
     def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:
         self._need(g, torch.bfloat16, "gelu_gate g")

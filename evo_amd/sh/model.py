@@ -268,8 +268,7 @@ class StripedHyena(nn.Module):
     def _mlp_residual_(self, blk, x2d, bias):
         ops = self.ops
         n2 = ops.rmsnorm(x2d, bias, blk.post_norm.scale, self.eps)       # x += bias (in place); n2 = norm(x)
-        g = ops.linear(n2, blk.mlp._w12, None)
-        a = ops.gelu_gate(g)
+        a = ops.mlp_gate(n2, blk.mlp._w12)
         ops.linear_residual_(x2d, a, blk.mlp._w3)
 
     def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams]):

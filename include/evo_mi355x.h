@@ -143,6 +143,13 @@ int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, cons
 int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                          int64_t M, int64_t N, int64_t K, void* stream);
 
+/* ---- gated MLP input, decode form ---------------------------------------------------------------------------
+ * replaces the l1 / l2 GEMV pair + gelu * mul of the single-token forward   [REF evo/configs/evo-1-8k-base_inference.yml:38;
+ *                                                                          evo/generation.py:151-155]
+ * a [M, I] bf16 = gelu_erf(x . W1^T) * (x . W2^T) with w12 [2I, K] = [W1; W2] bf16, x [M, K] bf16; 1 <= M <= 4,
+ * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them. */
+int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, void* stream);
+
 /* ---- gated MLP activation ---------------------------------------------------------------------------
  * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]
  * g [M, 2*I] bf16 = [l1 x | l2 x]  ->  a [M, I] bf16 = gelu_erf(g[:, :I]) * g[:, I:]. */

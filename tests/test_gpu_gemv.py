@@ -35,3 +35,27 @@ def test_linear_small_m(M, N, K, mode):
     err = (got - ref).abs()
     assert (err <= ref.abs() * 2 ** -8 + 2e-3 * ref.abs().max()).all()
     assert ((got - ref).norm() / ref.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("I,K", [(11008, 4096), (40, 264), (8, 8)])
+def test_mlp_gate_fused_matches_unfused_and_fp64(M, I, K):
+    """gelu(x W1^T) * (x W2^T) in one weight-streaming launch (M <= 4) == dense layer + gate kernel, and both within
+    bf16 rounding of fp64 (M = 6 exercises the unfused fallback of the same call)."""
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    g = torch.Generator().manual_seed(M * 77 + I + K)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w12 = (torch.randn(2 * I, K, generator=g) * (1.5 / K ** 0.5)).bfloat16().to(DEV)
+    got = ops.mlp_gate(x, w12)
+    unfused = ops.gelu_gate(ops.linear(x, w12, None))
+    assert got.shape == (M, I) and got.dtype == torch.bfloat16
+    # the two paths sum K in different orders: a product may round to the neighbouring bf16, then the gate output too
+    d = (got.double() - unfused.double()).abs()
+    assert bool((d <= unfused.double().abs() * 2.0 ** -6 + 1e-3 * unfused.double().abs().max()).all())
+    p = x.double() @ w12.double().t()
+    u, v = p[:, :I].bfloat16().double(), p[:, I:].bfloat16().double()
+    want = 0.5 * u * (1 + torch.erf(u / 2 ** 0.5)) * v
+    err = (got.double() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -6 + 2e-3 * want.abs().max()).all())
+    assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
