@@ -115,6 +115,91 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     }
 }
 
+// ---- RMSNorm folded into the layer that consumes it (decode form): y = bf16(scale * x / (rms(x) + eps)) . W^T + bias.
+// Every wave first reduces sum(x^2) with the rmsnorm kernel's own lane -> element mapping and summation order (so the
+// normalised row is bit-identical to what that kernel would have stored), then streams its R rows of W while it
+// rebuilds the normalised x slice by slice in registers -- one launch instead of two per block.
+template <int M, int R>
+__global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
+                                                        const uint4* __restrict__ w, const uint16_t* __restrict__ bias,
+                                                        uint16_t* __restrict__ y, int N, int nvec, float eps, float inv_sqrt_d) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    if (n0 >= N) return;
+    const uint4* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t n = n0 + r < N ? n0 + r : N - 1;
+        wrow[r] = w + n * nvec;
+    }
+    float inv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        float ss = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const uint4 xv = x[(int64_t)m * nvec + v];
+            const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        ss = wave_sum(ss);
+        inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+    }
+    auto normed = [&](int m, int v) {
+        const uint4 xv = x[(int64_t)m * nvec + v], sv = scale[v];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
+        o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv[m]), bf_hi(sv.y) * (bf_hi(xv.y) * inv[m]));
+        o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv[m]), bf_hi(sv.z) * (bf_hi(xv.z) * inv[m]));
+        o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
+        return o;
+    };
+    float acc[R][M];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+    int v = lane;
+    for (; v + 64 < nvec; v += 128) {
+        uint4 w0[R], w1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+        }
+    }
+    for (; v < nvec; v += 64) {
+        uint4 w0[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) w0[r] = ld_stream(wrow[r] + v);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = normed(m, v);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t n = n0 + r;
+            if (n < N) {
+                const float b = bias ? bf_to_f(bias[n]) : 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) y[(int64_t)m * N + n] = f_to_bf(acc[r][m] + b);
+            }
+        }
+    }
+}
+
 // ---- gated MLP input, decode form: a[m][n] = gelu(x_m . W1_n) * (x_m . W2_n) with W12 = [W1; W2] ([2I, K]).  Same
 // streaming loop as gemv_kernel; a wave owns 2 output columns = rows (n, n+1) of W1 and (I+n, I+n+1) of W2, rounds both
 // dot products to bf16 (what the unfused GEMM stores) and applies the gate -- one launch instead of two per block.
@@ -252,6 +337,25 @@ static void gemv_launch(const void* x, const void* w, const void* bias, const vo
     else
         hipLaunchKernelGGL((gemv_kernel<M, R, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)x,
                            (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)y, (int)N, (int)(K / 8));
+}
+
+extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w, const void* bias, void* y,
+                                            int64_t M, int64_t N, int64_t K, float eps, void* stream) {
+    if (M < 1 || M > 4 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(((N + 3) / 4 + 3) / 4)), block(256);
+    const float isd = 1.0f / sqrtf((float)K);
+#define EVO_NL(MM)                                                                                            \
+    hipLaunchKernelGGL((gemv_norm_kernel<MM, 4>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale,    \
+                       (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd)
+    switch (M) {
+        case 1: EVO_NL(1); break;
+        case 2: EVO_NL(2); break;
+        case 3: EVO_NL(3); break;
+        default: EVO_NL(4); break;
+    }
+#undef EVO_NL
+    return evo_launch_status();
 }
 
 extern "C" int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K,

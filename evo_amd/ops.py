@@ -36,6 +36,7 @@ _SIGNATURES = {
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -435,6 +436,22 @@ class HipOps:
                 part_o.data_ptr(), part_ml.data_ptr(), n_splits, 1.0 / math.sqrt(hd), _stream()),
                 "evo_attn_decode_bf16")
         return o
+
+    def norm_linear(self, x: torch.Tensor, scale: torch.Tensor, eps: float, w: torch.Tensor,
+                    b: Optional[torch.Tensor] = None, mfma: bool = False) -> torch.Tensor:
+        """linear(rmsnorm(x) * scale, w, b).  Decode-sized batches (M <= 4) with a wide layer take ONE weight-streaming
+        launch that rebuilds the normalised row on the fly; everything else is the two kernels."""
+        M, K = x.shape
+        if (1 <= M <= 4 and w.shape[0] > 4096 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+                and scale.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and scale.is_contiguous()
+                and K % 8 == 0):
+            y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device)
+            with self._t("gemv_norm"):
+                _check(self.lib.evo_norm_linear_small_m_bf16(x.data_ptr(), scale.data_ptr(), w.data_ptr(), _ptr(b),
+                                                             y.data_ptr(), M, w.shape[0], K, float(eps), _stream()),
+                       "evo_norm_linear_small_m_bf16")
+            return y
+        return self.linear(self.rmsnorm(x, None, scale, eps), w, b, mfma=mfma)
 
     def mlp_gate(self, x: torch.Tensor, w12: torch.Tensor) -> torch.Tensor:
         """a [M, I] = gelu(x @ W1^T) * (x @ W2^T), w12 = [W1; W2] ([2I, K]).  Decode-sized batches (M <= 4) take ONE

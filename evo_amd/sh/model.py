@@ -275,8 +275,7 @@ class StripedHyena(nn.Module):
         ops = self.ops
         D, H = self.hidden_size, self.num_heads
         f = blk.filter
-        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
-        z = ops.linear(n1, blk.projections.weight, blk.projections.bias)          # [B*T, 3D]
+        z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
         have_state = cache is not None and i in cache.fir_state_dict
         if have_state and T == 1:
             y = ops.hyena_step(z, cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
@@ -321,8 +320,7 @@ class StripedHyena(nn.Module):
         ops = self.ops
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         mha = blk.inner_mha_cls
-        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
-        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
+        qkv = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
         off = int(cache.seqlen_offset) if cache is not None else 0
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]

@@ -143,6 +143,14 @@ int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, cons
 int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                          int64_t M, int64_t N, int64_t K, void* stream);
 
+/* ---- RMSNorm + dense layer, decode form ----------------------------------------------------------------------
+ * replaces the pre-mixer RMSNorm and the projection GEMV of the single-token forward     [REF evo/generation.py:151-155;
+ *                                                                                   evo/configs/evo-1-8k-base_inference.yml:13]
+ * y [M, N] = bf16(scale * x / (rms(x) + eps)) . w [N, K]^T (+ bias [N]);  1 <= M <= 4, K % 8 == 0, all bf16.  The
+ * normalised row is bit-identical to what evo_rmsnorm_bf16 stores (same reduction order). */
+int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w, const void* bias, void* y,
+                                 int64_t M, int64_t N, int64_t K, float eps, void* stream);
+
 /* ---- gated MLP input, decode form ---------------------------------------------------------------------------
  * replaces the l1 / l2 GEMV pair + gelu * mul of the single-token forward   [REF evo/configs/evo-1-8k-base_inference.yml:38;
  *                                                                          evo/generation.py:151-155]

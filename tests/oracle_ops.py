@@ -61,6 +61,9 @@ class OracleOps:
     def attention(self, q, k, v, q_pos0):
         return self._o(R.op_attention(q, k, v, q_pos0))
 
+    def norm_linear(self, x, scale, eps, w, b=None, mfma=False):
+        return self.linear(self.rmsnorm(x, None, scale, eps), w, b)
+
     def mlp_gate(self, x, w12):
         return self.gelu_gate(self.linear(x, w12, None))
 

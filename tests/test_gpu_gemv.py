@@ -59,3 +59,24 @@ def test_mlp_gate_fused_matches_unfused_and_fp64(M, I, K):
     err = (got.double() - want).abs()
     assert bool((err <= want.abs() * 2.0 ** -6 + 2e-3 * want.abs().max()).all())
     assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 7])
+@pytest.mark.parametrize("N,K", [(12288, 4096), (4104, 264)])
+def test_norm_linear_fused_is_bitwise_the_two_kernels(M, N, K):
+    """RMSNorm folded into the weight-streaming dense layer (M <= 4, N > 4096): the normalised row is rebuilt with the
+    rmsnorm kernel's own reduction order, so the result equals rmsnorm -> linear bit for bit (M = 7: the fallback)."""
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    x = (torch.randn(M, K, generator=g) * 3).bfloat16().to(DEV)
+    scale = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV)
+    got = ops.norm_linear(x, scale, 1e-6, w, b)
+    two = ops.linear(ops.rmsnorm(x.clone(), None, scale, 1e-6), w, b)
+    assert torch.equal(got, two)
+    xd = x.double()
+    n = (scale.double() * xd / (xd.pow(2).mean(-1, keepdim=True).sqrt() + 1e-6)).bfloat16().double()
+    want = n @ w.double().t() + b.double()
+    assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
