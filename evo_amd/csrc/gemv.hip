@@ -203,13 +203,41 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
 // ---- gated MLP input, decode form: a[m][n] = gelu(x_m . W1_n) * (x_m . W2_n) with W12 = [W1; W2] ([2I, K]).  Same
 // streaming loop as gemv_kernel; a wave owns 2 output columns = rows (n, n+1) of W1 and (I+n, I+n+1) of W2, rounds both
 // dot products to bf16 (what the unfused GEMM stores) and applies the gate -- one launch instead of two per block.
-template <int M>
-__global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
-                                                        uint16_t* __restrict__ a, int I, int nvec) {
+// NORM: x is the un-normalised residual row and `scale` the RMSNorm weight (same fold as gemv_norm_kernel).
+template <int M, bool NORM>
+__global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
+                                                        const uint4* __restrict__ w, uint16_t* __restrict__ a, int I,
+                                                        int nvec, float eps, float inv_sqrt_d) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
     if (n0 >= I) return;
+    float inv[M];
+    if (NORM) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float ss = 0.f;
+            for (int v = lane; v < nvec; v += 64) {
+                const uint4 xv = x[(int64_t)m * nvec + v];
+                const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+            }
+            ss = wave_sum(ss);
+            inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+        }
+    }
+    auto xin = [&](int m, int v) {
+        const uint4 xv = x[(int64_t)m * nvec + v];
+        if (!NORM) return xv;
+        const uint4 sv = scale[v];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
+        o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv[m]), bf_hi(sv.y) * (bf_hi(xv.y) * inv[m]));
+        o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv[m]), bf_hi(sv.z) * (bf_hi(xv.z) * inv[m]));
+        o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
+        return o;
+    };
     const uint4* wrow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -228,7 +256,7 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         for (int r = 0; r < 4; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const uint4 x0 = x[(int64_t)m * nvec + v], x1 = x[(int64_t)m * nvec + v + 64];
+            const uint4 x0 = xin(m, v), x1 = xin(m, v + 64);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
         }
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         for (int r = 0; r < 4; ++r) w0[r] = ld_stream(wrow[r] + v);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const uint4 x0 = x[(int64_t)m * nvec + v];
+            const uint4 x0 = xin(m, v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
         }
@@ -358,18 +386,37 @@ extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, co
     return evo_launch_status();
 }
 
+static int mlp_gate_launch(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
+                           float eps, hipStream_t s) {
+    if (M < 1 || M > 4 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
+    const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
+    const float isd = 1.0f / sqrtf((float)K);
+#define EVO_MG(MM)                                                                                            \
+    if (scale)                                                                                                \
+        hipLaunchKernelGGL((gemv_gate_kernel<MM, true>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd);                  \
+    else                                                                                                      \
+        hipLaunchKernelGGL((gemv_gate_kernel<MM, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)nullptr, \
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), 0.f, 0.f)
+    switch (M) {
+        case 1: EVO_MG(1); break;
+        case 2: EVO_MG(2); break;
+        case 3: EVO_MG(3); break;
+        default: EVO_MG(4); break;
+    }
+#undef EVO_MG
+    return evo_launch_status();
+}
+
 extern "C" int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
                                          void* stream) {
-    if (M < 1 || M > 4 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
-    switch (M) {
-        case 1: hipLaunchKernelGGL(gemv_gate_kernel<1>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
-        case 2: hipLaunchKernelGGL(gemv_gate_kernel<2>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
-        case 3: hipLaunchKernelGGL(gemv_gate_kernel<3>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
-        default: hipLaunchKernelGGL(gemv_gate_kernel<4>, grid, block, 0, s, (const uint4*)x, (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8)); break;
-    }
-    return evo_launch_status();
+    return mlp_gate_launch(x, nullptr, w12, a, M, I, K, 0.f, (hipStream_t)stream);
+}
+
+extern "C" int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, const void* w12, void* a, int64_t M,
+                                              int64_t I, int64_t K, float eps, void* stream) {
+    if (!scale) return -1;
+    return mlp_gate_launch(x, scale, w12, a, M, I, K, eps, (hipStream_t)stream);
 }
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,

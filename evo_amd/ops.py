@@ -37,6 +37,7 @@ _SIGNATURES = {
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
+    "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -207,10 +208,15 @@ class HipOps:
             else:
                 torch.mm(x, w.t(), out=y)
 
-    def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor, mfma: bool = False) -> torch.Tensor:
-        """res += x @ w^T (fp32 accumulate, one rounding), in place."""
+    def linear_residual_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor, mfma: bool = False,
+                         bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """res += x @ w^T (+ bias) (fp32 accumulate, one rounding), in place.  `bias` is for the decode path, where the
+        weight-streaming kernel adds it in the same pass."""
         if self._use_small_m(x, w) and res.is_contiguous():
-            return self._linear_small_m(x, w, None, res)
+            return self._linear_small_m(x, w, bias, res)
+        if bias is not None:
+            self.linear_residual_(res, x, w, mfma)
+            return res.add_(bias)
         r = self._tail_rows(x, w) if res.is_contiguous() else 0
         if r:
             M = x.shape[0]
@@ -453,18 +459,28 @@ class HipOps:
             return y
         return self.linear(self.rmsnorm(x, None, scale, eps), w, b, mfma=mfma)
 
-    def mlp_gate(self, x: torch.Tensor, w12: torch.Tensor) -> torch.Tensor:
-        """a [M, I] = gelu(x @ W1^T) * (x @ W2^T), w12 = [W1; W2] ([2I, K]).  Decode-sized batches (M <= 4) take ONE
-        weight-streaming launch; everything else is the dense layer followed by the gate kernel."""
+    def mlp_gate(self, x: torch.Tensor, w12: torch.Tensor, norm_scale: Optional[torch.Tensor] = None,
+                 eps: float = 0.0) -> torch.Tensor:
+        """a [M, I] = gelu(x' @ W1^T) * (x' @ W2^T), w12 = [W1; W2] ([2I, K]); x' = x, or rmsnorm(x) * norm_scale when
+        `norm_scale` is given.  Decode-sized batches (M <= 4) take ONE weight-streaming launch; everything else is
+        (norm,) dense layer and gate kernel."""
         M, K = x.shape
         I = w12.shape[0] // 2
         if (1 <= M <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and w12.dtype == torch.bfloat16 and x.is_contiguous()
-                and w12.is_contiguous() and K % 8 == 0 and I % 2 == 0):
+                and w12.is_contiguous() and K % 8 == 0 and I % 2 == 0
+                and (norm_scale is None or (norm_scale.dtype == torch.bfloat16 and norm_scale.is_contiguous()))):
             a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
             with self._t("gemv_gate"):
-                _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), w12.data_ptr(), a.data_ptr(), M, I, K, _stream()),
-                       "evo_mlp_gate_small_m_bf16")
+                if norm_scale is None:
+                    _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), w12.data_ptr(), a.data_ptr(), M, I, K,
+                                                              _stream()), "evo_mlp_gate_small_m_bf16")
+                else:
+                    _check(self.lib.evo_norm_mlp_gate_small_m_bf16(x.data_ptr(), norm_scale.data_ptr(), w12.data_ptr(),
+                                                                   a.data_ptr(), M, I, K, float(eps), _stream()),
+                           "evo_norm_mlp_gate_small_m_bf16")
             return a
+        if norm_scale is not None:
+            x = self.rmsnorm(x, None, norm_scale, eps)
         return self.gelu_gate(self.linear(x, w12, None))
 
     def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:

@@ -265,10 +265,24 @@ class StripedHyena(nn.Module):
                 torch.sin(freqs).to(torch.bfloat16).float().contiguous())
 
     # ------------------------------------------------------------------ blocks
+    DECODE_ROWS = 4          # batches this small take the fused single-token launches (csrc/gemv.hip)
+
+    def _mixer_out_(self, blk, x2d, y, w, bias, mfma=False):
+        """x += y @ w^T (the mixer's output projection); returns the bias still to be added (folded into the next
+        RMSNorm pass for prefill-sized batches, into this launch for decode-sized ones)."""
+        if x2d.shape[0] <= self.DECODE_ROWS:
+            self.ops.linear_residual_(x2d, y, w, mfma=mfma, bias=bias)
+            return None
+        self.ops.linear_residual_(x2d, y, w, mfma=mfma)
+        return bias
+
     def _mlp_residual_(self, blk, x2d, bias):
         ops = self.ops
-        n2 = ops.rmsnorm(x2d, bias, blk.post_norm.scale, self.eps)       # x += bias (in place); n2 = norm(x)
-        a = ops.mlp_gate(n2, blk.mlp._w12)
+        if bias is None:                                                 # decode: norm + l1/l2 + gate in one launch
+            a = ops.mlp_gate(x2d, blk.mlp._w12, blk.post_norm.scale, self.eps)
+        else:
+            n2 = ops.rmsnorm(x2d, bias, blk.post_norm.scale, self.eps)   # x += bias (in place); n2 = norm(x)
+            a = ops.mlp_gate(n2, blk.mlp._w12)
         ops.linear_residual_(x2d, a, blk.mlp._w3)
 
     def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams]):
@@ -298,8 +312,7 @@ class StripedHyena(nn.Module):
                     tail = torch.cat([z3.new_zeros(B, K1 - T, 3 * D), tail], dim=1)
                 cache.fir_state_dict[i] = tail.transpose(1, 2).contiguous()      # [B, 3D, 2]
                 cache.state_dict[i] = state
-        ops.linear_residual_(x2d, y, blk.out_filter_dense.weight)
-        self._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
+        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias))
 
     def _kv_buffer(self, cache: InferenceParams, i: int, B: int, need: int, like: torch.Tensor):
         H, hd = self.num_heads, self.head_dim
@@ -347,8 +360,7 @@ class StripedHyena(nn.Module):
                 a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
             else:
                 a = ops.attention(q, k, v, off).view(B * T, D)
-        ops.linear_residual_(x2d, a, mha.out_proj.weight, mfma=True)
-        self._mlp_residual_(blk, x2d, mha.out_proj.bias)
+        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias, mfma=True))
 
     # ------------------------------------------------------------------ forward
     def hidden_states(self, x: torch.Tensor, inference_params_dict=None) -> torch.Tensor:

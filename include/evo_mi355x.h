@@ -157,6 +157,10 @@ int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w
  * a [M, I] bf16 = gelu_erf(x . W1^T) * (x . W2^T) with w12 [2I, K] = [W1; W2] bf16, x [M, K] bf16; 1 <= M <= 4,
  * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them. */
 int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, void* stream);
+/* same with the post-mixer RMSNorm folded in: x is the residual row, `scale` [K] the norm weight (bit-identical to
+ * evo_rmsnorm_bf16 followed by evo_mlp_gate_small_m_bf16). */
+int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I,
+                                   int64_t K, float eps, void* stream);
 
 /* ---- gated MLP activation ---------------------------------------------------------------------------
  * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]

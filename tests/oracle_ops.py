@@ -23,8 +23,11 @@ class OracleOps:
             y = y + b.double()
         return self._o(y)
 
-    def linear_residual_(self, res, x, w, mfma=False):
-        res.copy_(self._o(res.double() + x.double() @ w.double().t()))
+    def linear_residual_(self, res, x, w, mfma=False, bias=None):
+        y = res.double() + x.double() @ w.double().t()
+        if bias is not None:
+            y = y + bias.double()
+        res.copy_(self._o(y))
         return res
 
     def embed(self, ids, weight):
@@ -64,7 +67,9 @@ class OracleOps:
     def norm_linear(self, x, scale, eps, w, b=None, mfma=False):
         return self.linear(self.rmsnorm(x, None, scale, eps), w, b)
 
-    def mlp_gate(self, x, w12):
+    def mlp_gate(self, x, w12, norm_scale=None, eps=0.0):
+        if norm_scale is not None:
+            x = self.rmsnorm(x, None, norm_scale, eps)
         return self.gelu_gate(self.linear(x, w12, None))
 
     def gelu_gate(self, g):

@@ -80,3 +80,30 @@ def test_norm_linear_fused_is_bitwise_the_two_kernels(M, N, K):
     n = (scale.double() * xd / (xd.pow(2).mean(-1, keepdim=True).sqrt() + 1e-6)).bfloat16().double()
     want = n @ w.double().t() + b.double()
     assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
+
+
+@pytest.mark.parametrize("M", [1, 3, 4])
+def test_norm_mlp_gate_fused_is_bitwise_norm_then_gate(M):
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    I, K = 11008, 4096
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 2).bfloat16().to(DEV)
+    scale = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    w12 = (torch.randn(2 * I, K, generator=g) * (1.5 / K ** 0.5)).bfloat16().to(DEV)
+    got = ops.mlp_gate(x, w12, scale, 1e-6)
+    two = ops.mlp_gate(ops.rmsnorm(x.clone(), None, scale, 1e-6), w12)
+    assert torch.equal(got, two)
+
+
+def test_linear_residual_with_bias_small_m():
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4096, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(4096, 4096, generator=g) / 64).bfloat16().to(DEV)
+    b = torch.randn(4096, generator=g).bfloat16().to(DEV)
+    r = torch.randn(2, 4096, generator=g).bfloat16().to(DEV)
+    want = r.double() + x.double() @ w.double().t() + b.double()
+    got = ops.linear_residual_(r.clone(), x, w, bias=b)
+    assert ((got.double() - want).abs() <= want.abs() * 2.0 ** -8 + 1e-2).all()
