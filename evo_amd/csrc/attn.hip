@@ -17,6 +17,7 @@
 //   Ks [64 keys][128 d] bf16, 16-byte slot XOR-swizzled by (key & 15)      -> ds_read_b128 A fragments
 //   Vt [128 d][64 keys] bf16, 8-byte  slot XOR-swizzled by ((d >> 1) & 15) -> ds_read_b64  A fragments
 // Entry point and reference citation: include/evo_mi355x.h.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/evo_mi355x.h"
 
@@ -326,6 +327,305 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
     }
 }
 
+// ====================================================================================================
+// Pipelined prefill kernel (query ranges longer than one 128-row block).  Same math and MFMA fragment layouts as
+// attn_fwd_kernel<false>; what changes is everything around them, following what the counters and the probes said about
+// that kernel: per 64-key tile it spends 255 VALU instructions -- 77 staging K/V through registers,
+// 48 swizzle address adds -- in phases that do not overlap its 32 MFMAs.
+//   * a workgroup is 8 waves = 256 query rows (256 flop per K/V byte); K/V tiles arrive through a 4-stage LDS ring filled
+//     by asynchronous global->LDS DMA three tiles ahead -- no staging registers, no transpose in registers.  The DMA is
+//     inline asm (a DMA hipcc can see gets s_waitcnt vmcnt(0) in front of every later LDS read), waits are counted
+//     (never a drain) and the pieces of a tile are issued ONE AT A TIME between the P.V MFMAs: all of them in a burst
+//     behind the barrier block every wave on the vector-memory issue queue (1150 -> 835 TFLOP/s; spread: ~1010);
+//   * both tiles are ROW-MAJOR with padded rows, so every fragment address is a per-lane base + an immediate:
+//       Kp [64 keys][272 B]  -> QK^T A fragments by ds_read_b128, conflict-free (16 keys -> 16 bank quads)
+//       Vp [64 keys][320 B]  -> P.V  A fragments by ds_read_b64_tr_b16 (hardware 4x4 transpose: the lane that
+//                               points at row i/4, columns 4(i%4).. of a [4 keys][16 d] block receives the 4
+//                               keys of column i), conflict-free (row stride = 16 mod 64 dwords);
+//   * software pipelining INSIDE a wave, in program order: 16 x {K read, QK^T(t+1) MFMA, exp/sum/pack of two
+//     scores of tile t} then 16 x {2 transpose reads, P.V(t) MFMA, one DMA piece every third}; masking (diagonal /
+//     ragged tiles), the row max and the exact O rescale sit outside those blocks.
+// Measured against attn_fwd_kernel<false> on the same box: +10...13 % at T = 131,073 (~0.98-1.01 vs 0.87-0.89 PFLOP/s),
+// +3...5 % at 8 x 8,193; bit-reproducible and bit-identical across query offsets / strides like the 128-row kernel.
+#define PQB 256
+#define PK_ROW 272
+#define PV_ROW 320
+#define PK_STAGE (KB * PK_ROW)          // 17,408 B = 17 DMA pieces of 1 KiB
+#define PV_STAGE (KB * PV_ROW)          // 20,480 B = 20 DMA pieces
+#define P_STAGE (PK_STAGE + PV_STAGE)   // 37,888 B
+#define P_NSTG 4                        // 151,552 B of LDS: one workgroup per CU
+#define P_NDMA_K 17
+#define P_NDMA (17 + 20)
+
+typedef short tr_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_s16x4* lds_tr_ptr_t;
+typedef __attribute__((address_space(3))) void* lds_void_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_void_ptr_t;
+
+// fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max per operand; the raw instruction is what is wanted
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// "at most K tiles' worth of this wave's DMA pieces still outstanding" (np = 4 or 5 pieces per tile per wave)
+#define P_WAIT(K)                                                                                    \
+    do {                                                                                             \
+        if (np == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (K)) : "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K)) : "memory");                          \
+    } while (0)
+#define P_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTG * P_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int np = wave + 32 < P_NDMA ? 5 : 4;                          // DMA pieces of this wave per tile
+
+    const int64_t Tk_ = a.Tk, q_pos0_ = a.q_pos0;
+    int qb, head, bat;
+    attn_block_map(a, qb, head, bat);
+    const int64_t q0 = (int64_t)qb * PQB;
+    const uint16_t* qp = a.q + bat * a.q_sb + head * a.q_sh;
+    const unsigned char* kp = (const unsigned char*)(a.k + bat * a.k_sb + head * a.k_sh);
+    const unsigned char* vp = (const unsigned char*)(a.v + bat * a.v_sb + head * a.v_sh);
+    const int64_t kst_b = a.k_st * 2, vst_b = a.v_st * 2;
+
+    const int64_t qrow = q0 + wave * 32 + l31;
+    const int64_t qrow_c = qrow < a.Tq ? qrow : a.Tq - 1;
+    uint4 qf[8];
+    {
+        const uint4* qr = (const uint4*)(qp + qrow_c * a.q_st);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = qr[2 * ks + half];
+    }
+    int64_t q_last = q0 + PQB - 1;
+    if (q_last > a.Tq - 1) q_last = a.Tq - 1;
+    int64_t max_key = q_last + q_pos0_;
+    if (max_key > Tk_ - 1) max_key = Tk_ - 1;
+    const int n_tiles = (int)(max_key / KB) + 1;
+    const int64_t wq_first = q0 + wave * 32 + q_pos0_;
+    const int64_t my_lim = qrow + q_pos0_;
+
+    // ---- DMA plan: the 37 one-KiB pieces of a (K, V) tile are dealt round-robin to the 8 waves ------------------
+    // piece j < 17 -> K bytes [j KiB, (j+1) KiB) of the stage; piece j >= 17 -> V bytes.  Per lane: the (row, column)
+    // its 16 bytes belong to; lanes that fall into row padding fetch the row's first granule (never read back).
+    // d_off[jj]: this lane's byte offset inside the (K or V) tile for its jj-th piece (full tiles); the ragged last
+    // tile recomputes it with the row clamped to the last valid key (those rows are masked out of the softmax).
+    auto piece_rc = [&](int jj, int& r, int& c, bool& is_k) {
+        const int j = wave + 8 * jj;
+        is_k = j < P_NDMA_K;
+        const int pos = (is_k ? j : j - P_NDMA_K) * 1024 + 16 * lane;
+        const int rowb = is_k ? PK_ROW : PV_ROW;
+        r = pos / rowb;
+        c = pos - r * rowb;
+        c = c < 256 ? c : 0;
+    };
+    uint32_t d_off[5];
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+        int r, c; bool is_k;
+        piece_rc(jj, r, c, is_k);
+        d_off[jj] = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)c;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // One DMA piece (1 KiB) of tile `tile`: SGPR tile base + per-lane 32-bit offset.  Issued from inline asm (a DMA the
+    // compiler can see makes it drain vmcnt before every later LDS read), and ONE AT A TIME between MFMAs: a burst of
+    // all of a tile's pieces behind the barrier blocks every wave on the vector-memory issue queue (1150 -> 835 TFLOP/s).
+    auto dma_piece = [&](int tile, int jj) {
+        const int j = wave + 8 * jj;
+        if (j < P_NDMA) {
+            const int64_t k0 = (int64_t)tile * KB;
+            const bool is_k = j < P_NDMA_K;
+            const unsigned char* base = is_k ? kp + k0 * kst_b : vp + k0 * vst_b;
+            uint32_t off = d_off[jj];
+            const int64_t left = Tk_ - 1 - k0;
+            if (left < KB - 1) {                                    // ragged last tile (wave-uniform, once per row block)
+                int r, c; bool ik;
+                piece_rc(jj, r, c, ik);
+                r = r < (int)left ? r : (int)left;
+                off = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)c;
+            }
+            const uint32_t dst = lds0 + (tile & (P_NSTG - 1)) * P_STAGE + j * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         ::"s"(dst), "v"(off), "s"(base) : "memory", "m0");
+        }
+    };
+    auto dma_tile = [&](int tile) {
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) dma_piece(tile, jj);
+    };
+
+    // per-lane fragment bases (everything else is an immediate)
+    const uint32_t k_rd = (uint32_t)(l31 * PK_ROW + half * 16);
+    const uint32_t v_rd = (uint32_t)(PK_STAGE + (((lane & 15) >> 2) + 4 * half) * PV_ROW +
+                                     (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+
+    f32x16_t oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16_t s_cur[2], s_nxt[2];
+
+    auto row_max = [&](const f32x16_t (&s)[2]) {
+        float t = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) t = max3_raw(t, s[kt][r], s[kt][r + 1]);
+        return t;
+    };
+
+    // ---- prologue: three tiles in flight, then S(0) = QK^T of tile 0 ----------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the Q fragment loads: keep the counted waits to DMA only
+    dma_tile(0);
+    if (n_tiles > 1) dma_tile(1);
+    if (n_tiles > 2) dma_tile(2);
+    if (n_tiles > 2) P_WAIT(2); else if (n_tiles > 1) P_WAIT(1); else P_WAIT(0);
+    P_BARRIER();
+    {
+        const unsigned char* kb = smem + k_rd;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_cur[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 kf = *(const uint4*)(kb + kt * (32 * PK_ROW) + ks * 32);
+                s_cur[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf), as_frag(qf[ks]), s_cur[kt], 0, 0, 0);
+            }
+        }
+    }
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // one tile; the score tiles ping-pong between the two trips of the unrolled loop below (no 32-register copy)
+    auto tile_body = [&](f32x16_t (&s_cur)[2], f32x16_t (&s_nxt)[2], const int tile) {
+        const int64_t k0 = (int64_t)tile * KB;
+        // tile+1 must have landed (this wave's pieces: counted wait; everyone's: barrier).  The same barrier says every
+        // wave is done with tile-1, whose ring slot tile+3 now takes.
+        if (tile + 1 < n_tiles) {
+            if (tile + 2 < n_tiles) P_WAIT(1); else P_WAIT(0);
+        }
+        P_BARRIER();
+        const bool dma_more = tile + 3 < n_tiles;
+
+        // diagonal / ragged tiles: mask and redo the row max (wave-uniform, rare)
+        if ((k0 + KB - 1 > wq_first) || (k0 + KB > Tk_)) {
+            const int64_t lim64 = (my_lim < Tk_ - 1 ? my_lim : Tk_ - 1) - k0;
+            const int lim = lim64 > 63 ? 63 : (lim64 < -1 ? -1 : (int)lim64);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    s_cur[kt][r] = kidx <= lim ? s_cur[kt][r] : -INFINITY;
+                }
+        }
+        // row max of the (masked) tile.  (Folding these 16 v_max3 under the P.V MFMAs of the previous tile made the
+        // result irreproducible from run to run -- the hand-written v_max3 then sits next to MFMAs whose hazards the
+        // compiler does not model for inline asm; here it costs ~1 % and is exact.)
+        float tmax = row_max(s_cur);
+        // running max and the (rare, exact) O rescale -- outside the pipelined blocks, which therefore have no branch
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax * a.scale_log2);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        if (__any(m_new > m_run)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = oacc[dt] * alpha;
+        }
+        m_run = m_new;
+
+        // ---- phase 1: 16 x { K fragment read (2 ahead) | QK^T(tile+1) MFMA | exp/sum/pack of 2 scores of tile } -------
+        // program order IS the schedule (sched_barrier after every chunk): a 32x32x16 MFMA holds the matrix pipe for 32
+        // cycles, which covers the chunk's 5 VALU + 1 LDS instructions
+        const bool more = tile + 1 < n_tiles;              // last trip: recompute a dummy tile from a resident stage
+        const unsigned char* kb = smem + ((more ? tile + 1 : tile) & (P_NSTG - 1)) * P_STAGE + k_rd;
+        const float nm = -m_use;
+        float psum_a = 0.f, psum_b = 0.f;
+        uint32_t pk[2][8];
+        // K fragments: the 8 of the first 32-key half up front; each register is refilled with the matching fragment of
+        // the second half right after its MFMA (>= 8 MFMA slots of slack: LDS latency under 8 waves of traffic is
+        // several hundred cycles)
+        uint4 kf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const uint4*)(kb + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kt = i >> 3, ks = i & 7;
+            s_nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[ks]), as_frag(qf[ks]),
+                                                                ks == 0 ? zero16 : s_nxt[kt], 0, 0, 0);     // C = inline 0
+            if (kt == 0) kf[ks] = *(const uint4*)(kb + 32 * PK_ROW + ks * 32);
+            {
+                // scalar f32 on purpose: beside MFMAs a v_pk_fma_f32 / v_pk_add_f32 costs more than the two scalar ops
+                const int r = 2 * ks;
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][r], a.scale_log2, nm));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][r + 1], a.scale_log2, nm));
+                psum_a += p0;
+                psum_b += p1;
+                pk[kt][ks] = pack_bf2(p0, p1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l_run = fmaf(l_run, alpha, psum_a + psum_b);
+
+        // ---- phase 2: 16 x { V^T fragment transpose-reads (1 ahead) | P.V(tile) MFMA | row max of 2 scores of tile+1 } ---
+        const unsigned char* vb = smem + (tile & (P_NSTG - 1)) * P_STAGE + v_rd;
+        // V^T fragments 4 MFMAs ahead (ring of 5 pairs)
+        tr_s16x4 va[5], vc[5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char* pn = vb + (4 * (j >> 2)) * (4 * PV_ROW) + (j & 3) * 64;
+            va[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
+            vc[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j + 4 < 16) {
+                const int g = (j + 4) >> 2, dtn = (j + 4) & 3;             // g = 2*kt + u  ->  key quads 4g + half (+2)
+                const unsigned char* pn = vb + (4 * g) * (4 * PV_ROW) + dtn * 64;
+                va[(j + 4) % 5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
+                vc[(j + 4) % 5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
+            }
+            const int g = j >> 2, dt = j & 3, kt = g >> 1, u = g & 1;
+            uint4 pf;
+            pf.x = pk[kt][4 * u]; pf.y = pk[kt][4 * u + 1]; pf.z = pk[kt][4 * u + 2]; pf.w = pk[kt][4 * u + 3];
+            const uint2 ua = __builtin_bit_cast(uint2, va[j % 5]), ub = __builtin_bit_cast(uint2, vc[j % 5]);
+            uint4 vf;
+            vf.x = ua.x; vf.y = ua.y; vf.z = ub.x; vf.w = ub.y;
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf), as_frag(pf), oacc[dt], 0, 0, 0);
+            if (dma_more && (j % 3) == 1) dma_piece(tile + 3, j / 3);     // chunks 1, 4, 7, 10, 13 -> pieces 0..4
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int tile = 0; tile < n_tiles; tile += 2) {
+        tile_body(s_cur, s_nxt, tile);
+        if (tile + 1 < n_tiles) tile_body(s_nxt, s_cur, tile + 1);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < a.Tq) {
+        uint16_t* orow = a.o + ((int64_t)(bat * a.Tq + qrow) * a.H + head) * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+                w.y = pack_bf2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+                *(uint2*)(orow + 32 * dt + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
 // merge the splits of one (batch, head): out[d] = sum_s O_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M)
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
@@ -365,12 +665,19 @@ extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void
     a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
     a.H = (int)H;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    a.n_qblocks = (int)((Tq + QB - 1) / QB);
     a.dyn_pos = nullptr; a.part_o = nullptr; a.part_ml = nullptr; a.n_splits = 1;
+    // long query ranges take the pipelined 256-row kernel (EVO_AMD_ATTN_PIPE=0 keeps everything on the 128-row one)
+    static const int pipe_on = [] { const char* e = getenv("EVO_AMD_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+    const int use_pipe = pipe_on && Tq > QB;
     a.nbh = (int)(B * H);
+    const int qblock = use_pipe ? PQB : QB;
+    a.n_qblocks = (int)((Tq + qblock - 1) / qblock);
     const int64_t n_wg = (int64_t)a.n_qblocks * a.nbh;
     if (n_wg > 0x7fffffff) return -1;
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    if (use_pipe)
+        hipLaunchKernelGGL(attn_fwd_pipe_kernel, dim3((unsigned)n_wg), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }
 
