@@ -356,6 +356,9 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
 #define P_NSTG 4                        // 151,552 B of LDS: one workgroup per CU
 #define P_NDMA_K 17
 #define P_NDMA (17 + 20)
+#ifndef P_VD
+#define P_VD 4                          // V^T fragment prefetch distance, in MFMAs
+#endif
 
 typedef short tr_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) tr_s16x4* lds_tr_ptr_t;
@@ -578,26 +581,26 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
 
         // ---- phase 2: 16 x { V^T fragment transpose-reads (1 ahead) | P.V(tile) MFMA | row max of 2 scores of tile+1 } ---
         const unsigned char* vb = smem + (tile & (P_NSTG - 1)) * P_STAGE + v_rd;
-        // V^T fragments 4 MFMAs ahead (ring of 5 pairs)
-        tr_s16x4 va[5], vc[5];
+        // V^T fragments P_VD MFMAs ahead (ring of P_VD + 1 pairs)
+        tr_s16x4 va[P_VD + 1], vc[P_VD + 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < P_VD; ++j) {
             const unsigned char* pn = vb + (4 * (j >> 2)) * (4 * PV_ROW) + (j & 3) * 64;
             va[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
             vc[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (j + 4 < 16) {
-                const int g = (j + 4) >> 2, dtn = (j + 4) & 3;             // g = 2*kt + u  ->  key quads 4g + half (+2)
+            if (j + P_VD < 16) {
+                const int g = (j + P_VD) >> 2, dtn = (j + P_VD) & 3;       // g = 2*kt + u  ->  key quads 4g + half (+2)
                 const unsigned char* pn = vb + (4 * g) * (4 * PV_ROW) + dtn * 64;
-                va[(j + 4) % 5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
-                vc[(j + 4) % 5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
+                va[(j + P_VD) % (P_VD + 1)] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
+                vc[(j + P_VD) % (P_VD + 1)] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
             }
             const int g = j >> 2, dt = j & 3, kt = g >> 1, u = g & 1;
             uint4 pf;
             pf.x = pk[kt][4 * u]; pf.y = pk[kt][4 * u + 1]; pf.z = pk[kt][4 * u + 2]; pf.w = pk[kt][4 * u + 3];
-            const uint2 ua = __builtin_bit_cast(uint2, va[j % 5]), ub = __builtin_bit_cast(uint2, vc[j % 5]);
+            const uint2 ua = __builtin_bit_cast(uint2, va[j % (P_VD + 1)]), ub = __builtin_bit_cast(uint2, vc[j % (P_VD + 1)]);
             uint4 vf;
             vf.x = ua.x; vf.y = ua.y; vf.z = ub.x; vf.w = ub.y;
             oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf), as_frag(pf), oacc[dt], 0, 0, 0);
