@@ -418,50 +418,53 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
     // ---- DMA plan: the 37 one-KiB pieces of a (K, V) tile are dealt round-robin to the 8 waves ------------------
     // piece j < 17 -> K bytes [j KiB, (j+1) KiB) of the stage; piece j >= 17 -> V bytes.  Per lane: the (row, column)
     // its 16 bytes belong to; lanes that fall into row padding fetch the row's first granule (never read back).
-    // d_off[jj]: this lane's byte offset inside the (K or V) tile for its jj-th piece (full tiles); the ragged last
-    // tile recomputes it with the row clamped to the last valid key (those rows are masked out of the softmax).
-    auto piece_rc = [&](int jj, int& r, int& c, bool& is_k) {
-        const int j = wave + 8 * jj;
-        is_k = j < P_NDMA_K;
-        const int pos = (is_k ? j : j - P_NDMA_K) * 1024 + 16 * lane;
-        const int rowb = is_k ? PK_ROW : PV_ROW;
-        r = pos / rowb;
-        c = pos - r * rowb;
-        c = c < 256 ? c : 0;
-    };
+    // d_off[jj]: this lane's byte offset inside the (K or V) tile for its jj-th piece (row * row stride + column; pad
+    // lanes re-fetch the row's first granule).
     uint32_t d_off[5];
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj) {
-        int r, c; bool is_k;
-        piece_rc(jj, r, c, is_k);
-        d_off[jj] = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)c;
+        const int j = wave + 8 * jj;
+        const bool is_k = j < P_NDMA_K;
+        const int pos = (is_k ? j : j - P_NDMA_K) * 1024 + 16 * lane;
+        const int rowb = is_k ? PK_ROW : PV_ROW;
+        const int r = pos / rowb, c = pos - r * rowb;
+        d_off[jj] = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)(c < 256 ? c : 0);
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    // One DMA piece (1 KiB) of tile `tile`: SGPR tile base + per-lane 32-bit offset.  Issued from inline asm (a DMA the
-    // compiler can see makes it drain vmcnt before every later LDS read), and ONE AT A TIME between MFMAs: a burst of
-    // all of a tile's pieces behind the barrier blocks every wave on the vector-memory issue queue (1150 -> 835 TFLOP/s).
-    auto dma_piece = [&](int tile, int jj) {
-        const int j = wave + 8 * jj;
-        if (j < P_NDMA) {
-            const int64_t k0 = (int64_t)tile * KB;
-            const bool is_k = j < P_NDMA_K;
-            const unsigned char* base = is_k ? kp + k0 * kst_b : vp + k0 * vst_b;
-            uint32_t off = d_off[jj];
-            const int64_t left = Tk_ - 1 - k0;
-            if (left < KB - 1) {                                    // ragged last tile (wave-uniform, once per row block)
-                int r, c; bool ik;
-                piece_rc(jj, r, c, ik);
-                r = r < (int)left ? r : (int)left;
-                off = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)c;
-            }
-            const uint32_t dst = lds0 + (tile & (P_NSTG - 1)) * P_STAGE + j * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         ::"s"(dst), "v"(off), "s"(base) : "memory", "m0");
-        }
+    // Buffer descriptors of one tile: base = first row of the tile, num_records = bytes up to the end of the last VALID
+    // key (0 past the end of the sequence).  The hardware bounds check returns zeros for everything beyond -- the ragged
+    // last tile needs no clamping, and a tile that does not exist costs a DMA of zeros into a stage nobody reads, so
+    // every trip of the tile loop issues the same instructions (branch-free blocks, constant vmcnt counts).
+    typedef int srd_t __attribute__((ext_vector_type(4)));
+    auto tile_srd = [&](const unsigned char* base, int64_t st_b, int tile) {
+        const int64_t k0 = (int64_t)tile * KB;
+        int64_t rows = Tk_ - k0;
+        rows = rows > KB ? KB : rows;
+        const uint64_t a64 = (uint64_t)(base + k0 * st_b);
+        srd_t d;
+        d[0] = (int)(uint32_t)a64;
+        d[1] = (int)(uint32_t)(a64 >> 32);
+        d[2] = rows > 0 ? (int)((rows - 1) * st_b + 256) : 0;
+        d[3] = 0x00020000;
+        return d;
     };
+    // One DMA piece (1 KiB).  Inline asm (a DMA the compiler can see makes it drain vmcnt before every later LDS read),
+    // and issued ONE AT A TIME between MFMAs: all of a tile's pieces in a burst behind the barrier block every wave on the
+    // vector-memory issue queue (1150 -> 835 TFLOP/s).
+#define P_DMA_PIECE(KSRD, VSRD, STAGE_LDS, JJ)                                                                \
+    {                                                                                                         \
+        const int j_ = wave + 8 * (JJ);                                                                       \
+        if ((JJ) < 4 || j_ < P_NDMA) {                              /* (only piece 4 of waves 5..7 is absent) */ \
+            const srd_t d_ = j_ < P_NDMA_K ? (KSRD) : (VSRD);                                                 \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"             \
+                         ::"s"((STAGE_LDS) + j_ * 1024), "v"(d_off[JJ]), "s"(d_) : "memory", "m0");           \
+        }                                                                                                     \
+    }
     auto dma_tile = [&](int tile) {
+        const srd_t ks_ = tile_srd(kp, kst_b, tile), vs_ = tile_srd(vp, vst_b, tile);
+        const uint32_t st_ = lds0 + (tile & (P_NSTG - 1)) * P_STAGE;
 #pragma unroll
-        for (int jj = 0; jj < 5; ++jj) dma_piece(tile, jj);
+        for (int jj = 0; jj < 5; ++jj) P_DMA_PIECE(ks_, vs_, st_, jj);
     };
 
     // per-lane fragment bases (everything else is an immediate)
@@ -489,9 +492,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
     // ---- prologue: three tiles in flight, then S(0) = QK^T of tile 0 ----------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the Q fragment loads: keep the counted waits to DMA only
     dma_tile(0);
-    if (n_tiles > 1) dma_tile(1);
-    if (n_tiles > 2) dma_tile(2);
-    if (n_tiles > 2) P_WAIT(2); else if (n_tiles > 1) P_WAIT(1); else P_WAIT(0);
+    dma_tile(1);                                           // (tiles past the end: zero-length descriptors)
+    dma_tile(2);
+    P_WAIT(2);
     P_BARRIER();
     {
         const unsigned char* kb = smem + k_rd;
@@ -513,11 +516,10 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         const int64_t k0 = (int64_t)tile * KB;
         // tile+1 must have landed (this wave's pieces: counted wait; everyone's: barrier).  The same barrier says every
         // wave is done with tile-1, whose ring slot tile+3 now takes.
-        if (tile + 1 < n_tiles) {
-            if (tile + 2 < n_tiles) P_WAIT(1); else P_WAIT(0);
-        }
+        P_WAIT(1);                                         // every trip issues one tile's worth of pieces
         P_BARRIER();
-        const bool dma_more = tile + 3 < n_tiles;
+        const srd_t ksrd3 = tile_srd(kp, kst_b, tile + 3), vsrd3 = tile_srd(vp, vst_b, tile + 3);
+        const uint32_t st3 = lds0 + ((tile + 3) & (P_NSTG - 1)) * P_STAGE;
 
         // diagonal / ragged tiles: mask and redo the row max (wave-uniform, rare)
         if ((k0 + KB - 1 > wq_first) || (k0 + KB > Tk_)) {
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
             uint4 vf;
             vf.x = ua.x; vf.y = ua.y; vf.z = ub.x; vf.w = ub.y;
             oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf), as_frag(pf), oacc[dt], 0, 0, 0);
-            if (dma_more && (j % 3) == 1) dma_piece(tile + 3, j / 3);     // chunks 1, 4, 7, 10, 13 -> pieces 0..4
+            if ((j % 3) == 1) P_DMA_PIECE(ksrd3, vsrd3, st3, j / 3);       // chunks 1, 4, 7, 10, 13 -> pieces 0..4
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -613,6 +615,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         if (tile + 1 < n_tiles) tile_body(s_nxt, s_cur, tile + 1);
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (empty) DMA pieces: nothing may land after exit
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < a.Tq) {
