@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
 //   * software pipelining INSIDE a wave, in program order: 16 x {K read, QK^T(t+1) MFMA, exp/sum/pack of two
 //     scores of tile t} then 16 x {2 transpose reads, P.V(t) MFMA, one DMA piece every third}; masking (diagonal /
 //     ragged tiles), the row max and the exact O rescale sit outside those blocks.
-// Measured against attn_fwd_kernel<false> on the same box: +10...13 % at T = 131,073 (~0.98-1.01 vs 0.87-0.89 PFLOP/s),
-// +3...5 % at 8 x 8,193; bit-reproducible and bit-identical across query offsets / strides like the 128-row kernel.
+// Measured against attn_fwd_kernel<false>: 1.06-1.09 vs 0.87-0.89 PFLOP/s at T = 131,073, 0.82 vs 0.73 at 8 x 8,193;
+// bit-reproducible and bit-identical across query offsets / strides like the 128-row kernel.
 #define PQB 256
 #define PK_ROW 272
 #define PV_ROW 320
