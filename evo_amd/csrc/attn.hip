@@ -339,9 +339,10 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
 //     behind the barrier block every wave on the vector-memory issue queue (1150 -> 835 TFLOP/s; spread: ~1010);
 //   * both tiles are ROW-MAJOR with padded rows, so every fragment address is a per-lane base + an immediate:
 //       Kp [64 keys][272 B]  -> QK^T A fragments by ds_read_b128, conflict-free (16 keys -> 16 bank quads)
-//       Vp [64 keys][320 B]  -> P.V  A fragments by ds_read_b64_tr_b16 (hardware 4x4 transpose: the lane that
+//       Vp [64 keys][256 B]  -> P.V  A fragments by ds_read_b64_tr_b16 (hardware 4x4 transpose: the lane that
 //                               points at row i/4, columns 4(i%4).. of a [4 keys][16 d] block receives the 4
-//                               keys of column i), conflict-free (row stride = 16 mod 64 dwords);
+//                               keys of column i); un-padded, 64-byte blocks XOR-swizzled by (row & 3) on the
+//                               DMA's source side, so the read keeps per-d-tile bases + immediates;
 //   * software pipelining INSIDE a wave, in program order: 16 x {K read, QK^T(t+1) MFMA, exp/sum/pack of two
 //     scores of tile t} then 16 x {2 transpose reads, P.V(t) MFMA, one DMA piece every third}; masking (diagonal /
 //     ragged tiles), the row max and the exact O rescale sit outside those blocks.
@@ -349,13 +350,13 @@ __global__ __launch_bounds__(256, DECODE ? 1 : 2) void attn_fwd_kernel(AttnArgs 
 // bit-reproducible and bit-identical across query offsets / strides like the 128-row kernel.
 #define PQB 256
 #define PK_ROW 272
-#define PV_ROW 320
+#define PV_ROW 256                       // V rows un-padded: 64-byte block b of row r is stored at block b ^ (r & 3)
 #define PK_STAGE (KB * PK_ROW)          // 17,408 B = 17 DMA pieces of 1 KiB
-#define PV_STAGE (KB * PV_ROW)          // 20,480 B = 20 DMA pieces
-#define P_STAGE (PK_STAGE + PV_STAGE)   // 37,888 B
-#define P_NSTG 4                        // 151,552 B of LDS: one workgroup per CU
+#define PV_STAGE (KB * PV_ROW)          // 16,384 B = 16 DMA pieces
+#define P_STAGE (PK_STAGE + PV_STAGE)   // 33,792 B
+#define P_NSTG 4                        // 135,168 B of LDS: one workgroup per CU
 #define P_NDMA_K 17
-#define P_NDMA (17 + 20)
+#define P_NDMA (17 + 16)
 #ifndef P_VD
 #define P_VD 4                          // V^T fragment prefetch distance, in MFMAs
 #endif
@@ -427,8 +428,11 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         const bool is_k = j < P_NDMA_K;
         const int pos = (is_k ? j : j - P_NDMA_K) * 1024 + 16 * lane;
         const int rowb = is_k ? PK_ROW : PV_ROW;
-        const int r = pos / rowb, c = pos - r * rowb;
-        d_off[jj] = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)(c < 256 ? c : 0);
+        const int r = pos / rowb;
+        int c = pos - r * rowb;
+        if (is_k) c = c < 256 ? c : 0;                             // K: pad lanes re-fetch the row's first granule
+        else c = ((((c >> 6) ^ r) & 3) << 6) | (c & 63);           // V: the LDS slot's block holds source block b ^ (r & 3)
+        d_off[jj] = (uint32_t)r * (uint32_t)(is_k ? kst_b : vst_b) + (uint32_t)c;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // Buffer descriptors of one tile: base = first row of the tile, num_records = bytes up to the end of the last VALID
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
 #define P_DMA_PIECE(KSRD, VSRD, STAGE_LDS, JJ)                                                                \
     {                                                                                                         \
         const int j_ = wave + 8 * (JJ);                                                                       \
-        if ((JJ) < 4 || j_ < P_NDMA) {                              /* (only piece 4 of waves 5..7 is absent) */ \
+        if ((JJ) < 4 || j_ < P_NDMA) {                              /* (only piece 4 of waves 1..7 is absent) */ \
             const srd_t d_ = j_ < P_NDMA_K ? (KSRD) : (VSRD);                                                 \
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"             \
                          ::"s"((STAGE_LDS) + j_ * 1024), "v"(d_off[JJ]), "s"(d_) : "memory", "m0");           \
@@ -469,8 +473,15 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
 
     // per-lane fragment bases (everything else is an immediate)
     const uint32_t k_rd = (uint32_t)(l31 * PK_ROW + half * 16);
-    const uint32_t v_rd = (uint32_t)(PK_STAGE + (((lane & 15) >> 2) + 4 * half) * PV_ROW +
-                                     (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    // V^T fragment addresses: row r0 = (lane & 15) / 4 + 4 * half (+ 16 g, + 8: immediates), 64-byte block dt ^ (r0 & 3)
+    // (one base per d tile), 8 bytes at 32 * ((lane >> 4) & 1) + 8 * (lane & 3) inside the block.  The eight rows a
+    // ds_read_b64_tr_b16 touches fall on four distinct 64-byte bank windows, two rows each: 512 B in two passes.
+    uint32_t v_rd[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int r0 = ((lane & 15) >> 2) + 4 * half;
+        v_rd[dt] = (uint32_t)(PK_STAGE + r0 * PV_ROW + ((dt ^ (r0 & 3)) << 6) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    }
 
     f32x16_t oacc[4];
 #pragma unroll
@@ -582,12 +593,12 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         l_run = fmaf(l_run, alpha, psum_a + psum_b);
 
         // ---- phase 2: 16 x { V^T fragment transpose-reads (1 ahead) | P.V(tile) MFMA | row max of 2 scores of tile+1 } ---
-        const unsigned char* vb = smem + (tile & (P_NSTG - 1)) * P_STAGE + v_rd;
+        const unsigned char* vb = smem + (tile & (P_NSTG - 1)) * P_STAGE;
         // V^T fragments P_VD MFMAs ahead (ring of P_VD + 1 pairs)
         tr_s16x4 va[P_VD + 1], vc[P_VD + 1];
 #pragma unroll
         for (int j = 0; j < P_VD; ++j) {
-            const unsigned char* pn = vb + (4 * (j >> 2)) * (4 * PV_ROW) + (j & 3) * 64;
+            const unsigned char* pn = vb + v_rd[j & 3] + (4 * (j >> 2)) * (4 * PV_ROW);
             va[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
             vc[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
         }
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         for (int j = 0; j < 16; ++j) {
             if (j + P_VD < 16) {
                 const int g = (j + P_VD) >> 2, dtn = (j + P_VD) & 3;       // g = 2*kt + u  ->  key quads 4g + half (+2)
-                const unsigned char* pn = vb + (4 * g) * (4 * PV_ROW) + dtn * 64;
+                const unsigned char* pn = vb + v_rd[dtn] + (4 * g) * (4 * PV_ROW);
                 va[(j + P_VD) % (P_VD + 1)] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)pn);
                 vc[(j + P_VD) % (P_VD + 1)] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(pn + 2 * (4 * PV_ROW)));
             }
