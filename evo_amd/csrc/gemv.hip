@@ -200,6 +200,117 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     }
 }
 
+// ---- the whole Hyena mixer input of a decode step in one launch: pre-norm + projection + FIR/modal step + gate.
+// A wave owns TWO adjacent channels (c, c+1) of one head = six rows of the projection weight (x2, x1, v thirds), streams
+// them like gemv_norm_kernel, and then its first 2 M lanes (one per channel x batch row) run evo_hyena_step's arithmetic
+// on the six dot products -- same operations in the same order, so outputs and carried states are bit-identical to
+// evo_norm_linear_small_m_bf16 followed by evo_hyena_step.
+template <int M>
+__global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
+    const uint4* __restrict__ x, const uint4* __restrict__ scale, const uint4* __restrict__ w,
+    const uint16_t* __restrict__ bias, uint16_t* __restrict__ fir_state, float* __restrict__ iir_state,
+    const uint16_t* __restrict__ fir_w, const uint16_t* __restrict__ fir_b, const float* __restrict__ poles,
+    const float* __restrict__ residues, const uint16_t* __restrict__ dskip, uint16_t* __restrict__ y, int D, int nvec,
+    float eps, float inv_sqrt_d) {
+    constexpr int HDc = 128, NSc = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x * 4 + wave;                     // channel pair index over D / 2
+    if (pair >= D / 2) return;
+    const int h = pair / (HDc / 2), j0 = 2 * (pair - h * (HDc / 2));
+    const uint4* wrow[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r >> 1) * HDc + j0 + (r & 1)) * nvec;
+    float inv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        float ss = 0.f;
+        for (int v = lane; v < nvec; v += 64) {
+            const uint4 xv = x[(int64_t)m * nvec + v];
+            const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        ss = wave_sum(ss);
+        inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+    }
+    auto normed = [&](int m, int v) {
+        const uint4 xv = x[(int64_t)m * nvec + v], sv = scale[v];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
+        o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv[m]), bf_hi(sv.y) * (bf_hi(xv.y) * inv[m]));
+        o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv[m]), bf_hi(sv.z) * (bf_hi(xv.z) * inv[m]));
+        o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
+        return o;
+    };
+    float acc[6][M];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+    int v = lane;
+    for (; v + 64 < nvec; v += 128) {
+        uint4 w0[6], w1[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+        }
+    }
+    for (; v < nvec; v += 64) {
+        uint4 w0[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) w0[r] = ld_stream(wrow[r] + v);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4 x0 = normed(m, v);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (lane >= 2 * M) return;
+    const int e = lane & 1, m = lane >> 1;                       // this lane: channel j0 + e of batch row m
+    float f[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float d = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < M; ++mm)
+#pragma unroll
+            for (int ee = 0; ee < 2; ++ee) d = (m == mm && e == ee) ? acc[2 * g + ee][mm] : d;
+        const int c = h * 3 * HDc + g * HDc + j0 + e;            // channel in the 3D row
+        const uint16_t zraw = f_to_bf(d + bf_to_f(bias[c]));     // what the unfused projection stores
+        uint16_t* fs = fir_state + ((int64_t)m * 3 * D + c) * 2;
+        const float o0 = bf_to_f(fs[0]), o1 = bf_to_f(fs[1]);
+        f[g] = fmaf(bf_to_f(fir_w[c * 3 + 2]), bf_to_f(zraw),
+                    fmaf(bf_to_f(fir_w[c * 3 + 1]), o1, fmaf(bf_to_f(fir_w[c * 3]), o0, bf_to_f(fir_b[c]))));
+        fs[0] = fs[1];
+        fs[1] = zraw;
+    }
+    const int dch = h * HDc + j0 + e;
+    const float xv = f[1] * f[2];
+    float2* st = (float2*)iir_state + ((int64_t)m * D + dch) * NSc;
+    const float2* pp = (const float2*)poles + (int64_t)dch * NSc;
+    const float2* rp = (const float2*)residues + (int64_t)dch * NSc;
+    float accy = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSc; ++s) {
+        const float2 p = pp[s], r = rp[s], sv = st[s];
+        const float nr = fmaf(p.x, sv.x, fmaf(-p.y, sv.y, xv));
+        const float ni = fmaf(p.x, sv.y, p.y * sv.x);
+        st[s] = make_float2(nr, ni);
+        accy = fmaf(r.x, nr, fmaf(-r.y, ni, accy));
+    }
+    y[(int64_t)m * D + dch] = f_to_bf(fmaf(xv, bf_to_f(dskip[dch]), accy) * f[0]);
+}
+
 // ---- gated MLP input, decode form: a[m][n] = gelu(x_m . W1_n) * (x_m . W2_n) with W12 = [W1; W2] ([2I, K]).  Same
 // streaming loop as gemv_kernel; a wave owns 2 output columns = rows (n, n+1) of W1 and (I+n, I+n+1) of W2, rounds both
 // dot products to bf16 (what the unfused GEMM stores) and applies the gate -- one launch instead of two per block.
@@ -383,6 +494,29 @@ extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, co
         default: EVO_NL(4); break;
     }
 #undef EVO_NL
+    return evo_launch_status();
+}
+
+extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_scale, const void* proj_w, const void* proj_b,
+                                              void* fir_state, float* iir_state, const void* fir_w, const void* fir_b,
+                                              const float* poles, const float* residues, const void* dskip, void* y,
+                                              int64_t M, int64_t D, int64_t n_heads, float eps, void* stream) {
+    if (M < 1 || M > 4 || D <= 0 || D != n_heads * 128 || D % 8 != 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((D / 2 + 3) / 4)), block(256);
+    const float isd = 1.0f / sqrtf((float)D);
+#define EVO_HD(MM)                                                                                            \
+    hipLaunchKernelGGL((gemv_norm_hyena_kernel<MM>), grid, block, 0, s, (const uint4*)x, (const uint4*)norm_scale, \
+                       (const uint4*)proj_w, (const uint16_t*)proj_b, (uint16_t*)fir_state, iir_state,          \
+                       (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, residues, (const uint16_t*)dskip, \
+                       (uint16_t*)y, (int)D, (int)(D / 8), eps, isd)
+    switch (M) {
+        case 1: EVO_HD(1); break;
+        case 2: EVO_HD(2); break;
+        case 3: EVO_HD(3); break;
+        default: EVO_HD(4); break;
+    }
+#undef EVO_HD
     return evo_launch_status();
 }
 

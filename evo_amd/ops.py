@@ -38,6 +38,7 @@ _SIGNATURES = {
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
+    "evo_hyena_decode_fused_small_m": ([_PTR] * 12 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
 }
@@ -384,6 +385,28 @@ class HipOps:
         _check(self.lib.evo_hyena_step(z_t.data_ptr(), fir_state.data_ptr(), sr.data_ptr(), fir_w.data_ptr(),
                                        fir_b.data_ptr(), poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(),
                                        y.data_ptr(), B, D, n_heads, _stream()), "evo_hyena_step")
+        return y
+
+    def hyena_decode_fused(self, x, norm_scale, eps, proj_w, proj_b, fir_state, iir_state, fir_w, fir_b, poles,
+                           residues, dskip, n_heads: int) -> torch.Tensor:
+        """One decode token through pre-norm + projections + FIR/modal step + gate in ONE launch (M = batch <= 4);
+        states are updated in place.  Falls back to the two kernels otherwise."""
+        M, D = x.shape
+        ok = (1 <= M <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and proj_w.is_contiguous()
+              and proj_w.dtype == torch.bfloat16 and norm_scale.dtype == torch.bfloat16 and proj_b is not None
+              and fir_state.dtype == torch.bfloat16 and fir_state.is_contiguous() and fir_state.shape[0] == M
+              and iir_state.dtype == torch.complex64 and iir_state.is_contiguous() and iir_state.shape[0] == M
+              and D == n_heads * 128)
+        if not ok:
+            z = self.norm_linear(x, norm_scale, eps, proj_w, proj_b)
+            return self.hyena_step(z, fir_state, iir_state, fir_w, fir_b, poles, residues, dskip, n_heads)
+        y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+        sr = torch.view_as_real(iir_state)
+        with self._t("gemv_hyena"):
+            _check(self.lib.evo_hyena_decode_fused_small_m(
+                x.data_ptr(), norm_scale.data_ptr(), proj_w.data_ptr(), proj_b.data_ptr(), fir_state.data_ptr(),
+                sr.data_ptr(), fir_w.data_ptr(), fir_b.data_ptr(), poles.data_ptr(), residues.data_ptr(),
+                dskip.data_ptr(), y.data_ptr(), M, D, n_heads, float(eps), _stream()), "evo_hyena_decode_fused_small_m")
         return y
 
     def rope_(self, qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:

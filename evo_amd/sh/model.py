@@ -289,12 +289,13 @@ class StripedHyena(nn.Module):
         ops = self.ops
         D, H = self.hidden_size, self.num_heads
         f = blk.filter
-        z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
         have_state = cache is not None and i in cache.fir_state_dict
-        if have_state and T == 1:
-            y = ops.hyena_step(z, cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
-                               f._poles, f._residues, f.D, H)
+        if have_state and T == 1:                 # decode: norm + projections + FIR/modal step + gate in one launch
+            y = ops.hyena_decode_fused(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias,
+                                       cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
+                                       f._poles, f._residues, f.D, H)
         else:
+            z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
             z3 = z.view(B, T, 3 * D)
             halo = s0 = None
             if have_state:                      # continue a cached prefix with more than one token

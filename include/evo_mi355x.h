@@ -143,6 +143,16 @@ int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, cons
 int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                          int64_t M, int64_t N, int64_t K, void* stream);
 
+/* ---- Hyena mixer input of one decode step, fused ---------------------------------------------------------------
+ * replaces pre-norm + projections GEMV + step_fir + step_iir of the single-token forward   [REF evo/generation.py:111-114,138-155]
+ * x [M, D] bf16 residual rows (M = batch, 1 <= M <= 4), norm_scale [D], proj_w [3D, D], proj_b [3D] -> y [M, D] bf16;
+ * fir_state [M, 3D, 2] bf16 and iir_state [M, D, 8] complex64 are updated in place.  Bit-identical to
+ * evo_norm_linear_small_m_bf16 followed by evo_hyena_step. */
+int evo_hyena_decode_fused_small_m(const void* x, const void* norm_scale, const void* proj_w, const void* proj_b,
+                                   void* fir_state, float* iir_state, const void* fir_w, const void* fir_b,
+                                   const float* poles, const float* residues, const void* dskip, void* y,
+                                   int64_t M, int64_t D, int64_t n_heads, float eps, void* stream);
+
 /* ---- RMSNorm + dense layer, decode form ----------------------------------------------------------------------
  * replaces the pre-mixer RMSNorm and the projection GEMV of the single-token forward     [REF evo/generation.py:151-155;
  *                                                                                   evo/configs/evo-1-8k-base_inference.yml:13]

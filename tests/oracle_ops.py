@@ -67,6 +67,11 @@ class OracleOps:
     def norm_linear(self, x, scale, eps, w, b=None, mfma=False):
         return self.linear(self.rmsnorm(x, None, scale, eps), w, b)
 
+    def hyena_decode_fused(self, x, norm_scale, eps, proj_w, proj_b, fir_state, iir_state, fir_w, fir_b, poles, residues,
+                           dskip, n_heads):
+        z = self.norm_linear(x, norm_scale, eps, proj_w, proj_b)
+        return self.hyena_step(z, fir_state, iir_state, fir_w, fir_b, poles, residues, dskip, n_heads)
+
     def mlp_gate(self, x, w12, norm_scale=None, eps=0.0):
         if norm_scale is not None:
             x = self.rmsnorm(x, None, norm_scale, eps)

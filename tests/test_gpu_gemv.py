@@ -107,3 +107,34 @@ def test_linear_residual_with_bias_small_m():
     want = r.double() + x.double() @ w.double().t() + b.double()
     got = ops.linear_residual_(r.clone(), x, w, bias=b)
     assert ((got.double() - want).abs() <= want.abs() * 2.0 ** -8 + 1e-2).all()
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 5])
+def test_hyena_decode_fused_is_bitwise_the_separate_kernels(M):
+    """pre-norm + projections + FIR/modal step + gate in one launch == evo_norm_linear + evo_hyena_step, outputs AND the
+    carried states, bit for bit, over several consecutive tokens (M = 5: the fallback of the same call)."""
+    import math
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    D, H = 512, 4
+    g = torch.Generator().manual_seed(M)
+    scale = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16().to(DEV)
+    w = (torch.randn(3 * D, D, generator=g) / D ** 0.5).bfloat16().to(DEV)
+    b = (torch.randn(3 * D, generator=g) * 0.1).bfloat16().to(DEV)
+    fir_w = (torch.randn(3 * D, 3, generator=g) * 0.3).bfloat16().to(DEV)
+    fir_b = (torch.randn(3 * D, generator=g) * 0.1).bfloat16().to(DEV)
+    mag = 1.0 - 10.0 ** (-5.0 + 4.0 * torch.rand(D, 8, generator=g))
+    ang = (torch.rand(D, 8, generator=g) * 2 - 1) * math.pi
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous().to(DEV)
+    res = (torch.randn(D, 8, 2, generator=g) * 0.25).float().contiguous().to(DEV)
+    dskip = (torch.randn(D, generator=g) * 0.5).bfloat16().to(DEV)
+    fs_a = (torch.randn(M, 3 * D, 2, generator=g)).bfloat16().to(DEV)
+    st_a = torch.view_as_complex(torch.randn(M, D, 8, 2, generator=g).contiguous()).to(DEV)
+    fs_b, st_b = fs_a.clone(), st_a.clone()
+    for step in range(3):
+        x = (torch.randn(M, D, generator=g) * 2).bfloat16().to(DEV)
+        ya = ops.hyena_decode_fused(x, scale, 1e-6, w, b, fs_a, st_a, fir_w, fir_b, poles, res, dskip, H)
+        z = ops.linear(ops.rmsnorm(x.clone(), None, scale, 1e-6), w, b)
+        yb = ops.hyena_step(z, fs_b, st_b, fir_w, fir_b, poles, res, dskip, H)
+        assert torch.equal(ya, yb), f"step {step}"
+        assert torch.equal(fs_a, fs_b) and torch.equal(torch.view_as_real(st_a), torch.view_as_real(st_b))
