@@ -342,7 +342,7 @@ class StripedHyena(nn.Module):
             # position-independent decode step (hipGraph replay, continuous batching): one position PER ROW, in
             # device memory.  The rotary kernel indexes its table by token, so the B rows are presented as one
             # sequence of B tokens with the per-row table.
-            cos, sin = self._rotary_dyn(pos)
+            cos, sin = getattr(cache, "_rot_dyn", None) or self._rotary_dyn(pos)
             ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin)
             kv = cache.key_value_memory_dict[i][:B]
             kv[self._row_index(B, x2d.device), pos] = qkv[:, 0, 1:3]
@@ -375,11 +375,18 @@ class StripedHyena(nn.Module):
         h = ops.embed(x.to(self.device), self.embedding_layer.weight)             # [B*T, D]
         mha_c = inference_params_dict["mha"] if inference_params_dict is not None else None
         hy_c = inference_params_dict["hyena"] if inference_params_dict is not None else None
-        for i, blk in enumerate(self.blocks):
-            if isinstance(blk, _AttentionBlock):
-                self._attn_block(i, blk, h, B, T, mha_c)
-            else:
-                self._hyena_block(i, blk, h, B, T, hy_c)
+        dyn = T == 1 and mha_c is not None and getattr(mha_c, "pos_tensor", None) is not None
+        if dyn:                                   # one rotary table per decode step, shared by the attention layers
+            mha_c._rot_dyn = self._rotary_dyn(mha_c.pos_tensor)
+        try:
+            for i, blk in enumerate(self.blocks):
+                if isinstance(blk, _AttentionBlock):
+                    self._attn_block(i, blk, h, B, T, mha_c)
+                else:
+                    self._hyena_block(i, blk, h, B, T, hy_c)
+        finally:
+            if dyn:
+                mha_c._rot_dyn = None
         if self.norm is not None:
             h = ops.rmsnorm(h, None, self.norm.scale, self.eps)
         return h
