@@ -133,6 +133,13 @@ class DecodePool:
         if hasattr(m, "eval"):
             m.eval()
         n_tokens = int(n_tokens)
+        if n_tokens < 1 or int(n_sample_per_prompt) < 1:
+            raise ValueError("n_tokens and n_sample_per_prompt must be >= 1")
+        prompts = list(prompts)
+        if not prompts:
+            return [], [], []
+        if any((not isinstance(p, str)) or (len(p) == 0 and not prepend_bos) for p in prompts):
+            raise ValueError("every prompt must be a non-empty string (or use prepend_bos=True)")
         encoded = [prepare_batch([p], tok, prepend_bos=prepend_bos, device=str(dev))[0] for p in prompts]
         self._allocate(max(e.shape[1] for e in encoded) + n_tokens)
         # job = (output index, prompt index); the copies of one prompt are adjacent so that they share a prefill

@@ -91,3 +91,17 @@ def test_sample_many_cli_writes_reference_csv(tmp_path, monkeypatch, model_and_r
     assert [r[2] for r in got[1:]] == [seqs[0]] * 2 + [seqs[1]] * 2
     assert all(len(r[0]) == 32 for r in got[1:]) and len({r[0] for r in got[1:]}) == 4
     np.testing.assert_allclose([float(r[3]) for r in got[1:]], [scores[0]] * 2 + [scores[1]] * 2, rtol=1e-6)
+
+
+def test_pool_argument_validation_and_degenerate_jobs(model_and_reference):
+    m, seqs, scores = model_and_reference
+    pool = DecodePool(m, TOK, n_slots=2, top_k=1, top_p=1.0, temperature=0.0, device="cpu")
+    assert pool.generate([], n_tokens=5) == ([], [], [])
+    with pytest.raises(ValueError):
+        pool.generate(["ACGT"], n_tokens=0)
+    with pytest.raises(ValueError):
+        pool.generate(["ACGT", ""], n_tokens=3)
+    one, _, _ = pool.generate(PROMPTS[:3], n_tokens=1)               # every stream ends at its prefill
+    assert one == [s[:1] for s in seqs[:3]]
+    bos, sc, _ = pool.generate(["", "AC"], n_tokens=3, prepend_bos=True)   # an empty prompt is just the BOS token
+    assert len(bos) == 2 and all(len(s) == 3 for s in bos) and all(np.isfinite(sc))
