@@ -113,7 +113,7 @@ def cpu_baseline(nt=512, layers=(0, 1, 2, 3)):
         m(ids)                                           # warm-up (thread pools, oneDNN primitives)
         t0 = time.perf_counter()
         reps = 0
-        while reps < 3 and time.perf_counter() - t0 < 20.0:
+        while reps < 12 and time.perf_counter() - t0 < 20.0:
             m(ids)
             reps += 1
         dt = (time.perf_counter() - t0) / reps
