@@ -584,10 +584,12 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
                 const int r = 2 * ks;
                 const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][r], a.scale_log2, nm));
                 const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][r + 1], a.scale_log2, nm));
-                // (pinned: left to itself hipcc keeps all 32 p values alive and sums them in one dependent chain after the
-                //  pipelined blocks.  The operands are v_exp results, not MFMA results: no unmodelled hazard.)
-                asm volatile("v_add_f32 %0, %1, %0" : "+v"(psum_a) : "v"(p0));
-                asm volatile("v_add_f32 %0, %1, %0" : "+v"(psum_b) : "v"(p1));
+                // (pinned with an EMPTY asm: left to itself hipcc keeps all 32 p values alive and sums them in one dependent
+                //  chain after the pipelined blocks; a hand-written v_add would read the v_exp result without the wait state
+                //  the compiler inserts for its own instructions.)
+                psum_a += p0;
+                psum_b += p1;
+                asm volatile("" : "+v"(psum_a), "+v"(psum_b));
                 pk[kt][ks] = pack_bf2(p0, p1);
             }
             __builtin_amdgcn_sched_barrier(0);
