@@ -5,11 +5,15 @@ multi-GPU path at all, so this is new design, not a translation.
 Rank r owns tokens [r*Tl, min(T, (r+1)*Tl)), Tl = ceil(T/R), of ALL batch rows.  Embedding, RMSNorm, every
 GEMM, the MLP, the unembedding and the scoring tail are token-local -> no communication.  Per layer:
 
-  Hyena block   (1) 2-row halo of z from the previous rank (for the k=3 FIR)        all-gather of [B,2,3D] tails
+  Hyena block   (1) 2-row halo of z from the previous rank (for the k=3 FIR): ONE neighbour send/recv of [B,2,3D].
+                    The two tail rows are projected first by the weight-streaming kernel (M = 2B <= 16) and sent
+                    while the shard's big projection GEMM runs, so the exchange is off the critical path.
                 (2) stage 1 on the shard (zero carry-in) -> end state E_r [B,D,8] c64
                 (3) all-gather of the R end states (262 KB * B per rank: latency-, not bandwidth-bound)
                 (4) S_in(r) = sum_{q<r} p^{Tl*(r-1-q)} E_q   (exact: the filter is a finite sum of modes)
                 (5) stage 2: carry-add + apply kernel
+                Batch rows are cut into two groups: group A's all-gather (3) runs on RCCL's stream under group B's
+                stage-1 kernels, group B's under group A's stage 2.
   Attention     head <-> sequence all-to-all ("Ulysses") when n_heads % R == 0: every rank sends, per batch row,
                 the q,k,v of its token shard for head group g to rank g and receives the FULL sequence for its
                 own H/R heads; it runs ordinary causal attention on them (perfectly balanced: no causal
@@ -56,12 +60,42 @@ class DistComm:
             w = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=async_op)
         return out, (w if async_op else _Done())
 
-    def all_to_all(self, t: torch.Tensor, async_op: bool = False):
+    def all_to_all(self, t: torch.Tensor, async_op: bool = False, out: Optional[torch.Tensor] = None):
         """t [R, ...]: slice g goes to rank g; returns ([R, ...] with slice q received from rank q, work)."""
         t = t.contiguous()
-        out = torch.empty_like(t)
+        out = torch.empty_like(t) if out is None else out
         w = dist.all_to_all_single(out, t, group=self.group, async_op=async_op)
         return out, (w if async_op else _Done())
+
+    def shift_from_prev(self, t: torch.Tensor, async_op: bool = False):
+        """Point-to-point ring step without wrap-around: this rank's `t` goes to rank+1, the return value is rank-1's
+        `t` (None on rank 0).  One send + one recv per rank instead of an R-way gather."""
+        rank = dist.get_rank(self.group)
+        t = t.contiguous()
+        ops, out = [], None
+        if rank + 1 < self.world:
+            ops.append(dist.P2POp(dist.isend, t, dist.get_global_rank(self.group, rank + 1) if self.group else rank + 1,
+                                  self.group))
+        if rank > 0:
+            out = torch.empty_like(t)
+            ops.append(dist.P2POp(dist.irecv, out, dist.get_global_rank(self.group, rank - 1) if self.group else rank - 1,
+                                  self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if not async_op:
+            for w in works:
+                w.wait()
+            return out, _Done()
+        return out, _Works(works, keep=t)
+
+
+class _Works:
+    def __init__(self, works, keep=None):
+        self.works, self.keep = works, keep            # `keep`: the send buffer must outlive the transfer
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
 
 
 class SequenceParallelScorer:
@@ -70,10 +104,53 @@ class SequenceParallelScorer:
         self.rank, self.world = rank, world
         self.comm = comm if comm is not None else DistComm(group)
         self.attn_mode = "auto"          # "auto": Ulysses when n_heads % world == 0, else K/V all-gather
+        self.row_groups = 2              # Hyena end-state exchange is pipelined over this many groups of batch rows
         self._pow_cache = {}
+        self._bufs = {}
+        # comm_profile: every exchange is waited for right where it is posted and bracketed by device events, so the
+        # numbers are raw collective durations (bench.py's instrumented pass); off in the timed region
+        self.comm_profile = False
+        self.comm_events = {}
 
-    def _gather0(self, t: torch.Tensor, async_op: bool = False):
-        return self.comm.all_gather(t, async_op=async_op)
+    # ------------------------------------------------------------------ communication helpers
+    def _post(self, name, fn, *args, **kw):
+        """Post an exchange asynchronously; in comm_profile mode time it (post -> complete) on the device."""
+        if self.comm_profile and torch.cuda.is_available():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out, w = fn(*args, **kw)
+            w.wait()
+            b.record()
+            self.comm_events.setdefault(name, []).append((a, b))
+            return out, _Done()
+        return fn(*args, **kw)
+
+    def comm_summary(self):
+        """{name: (count, mean_ms)} of the exchanges timed in comm_profile mode (call after a synchronize)."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.comm_events.items()}
+
+    def _gather0(self, t: torch.Tensor, async_op: bool = False, name: str = "all_gather"):
+        return self._post(name, self.comm.all_gather, t, async_op=async_op)
+
+    def _shift(self, t: torch.Tensor):
+        """rank-1's `t` (None on rank 0), asynchronously."""
+        if hasattr(self.comm, "shift_from_prev"):
+            return self._post("halo_sendrecv", self.comm.shift_from_prev, t, async_op=True)
+        g, w = self._post("halo_allgather", self.comm.all_gather, t, async_op=True)   # communicators without P2P
+
+        class _Pick:
+            def __init__(s, g, w, r):
+                s.g, s.w, s.r = g, w, r
+
+            def wait(s):
+                return s.w.wait()
+        return (g[self.rank - 1] if self.rank > 0 else None), _Pick(g, w, self.rank)
+
+    def _buf(self, key, shape, like):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != like.dtype or b.device != like.device:
+            b = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return b
 
     # ------------------------------------------------------------------ shard geometry
     def shard(self, T: int):
@@ -82,15 +159,33 @@ class SequenceParallelScorer:
         t1 = min(T, t0 + Tl)
         return Tl, t0, t1
 
+    def check_geometry(self, T: int):
+        """Identical verdict on EVERY rank (before any collective): all shards non-empty, and every shard that feeds a
+        successor holds at least the 2 rows of the FIR halo."""
+        Tl = (T + self.world - 1) // self.world
+        if (self.world - 1) * Tl >= T or (self.world > 1 and Tl < 2):
+            raise ValueError(f"cannot shard {T} tokens over {self.world} ranks: ceil(T/R) = {Tl} leaves an empty or "
+                             f"sub-halo shard; use fewer ranks")
+        return Tl
+
     def _pole_powers(self, poles: torch.Tensor, Tl: int) -> torch.Tensor:
-        """[R, D, 8] complex128: p^(Tl*k) for k = 0..R-1 (fp64: the carry must stay exact over the whole context)."""
+        """[R, D, 8] complex128: p^(Tl*k) for k = 0..R-1 by integer exponentiation in fp64 (exact for p = 0 too;
+        the carry must stay exact over the whole context)."""
         key = (poles.data_ptr(), Tl)
         hit = self._pow_cache.get(key)
         if hit is None:
             p = torch.view_as_complex(poles.double().contiguous())
-            logp = torch.log(p)
-            k = torch.arange(self.world, device=poles.device, dtype=torch.float64)
-            hit = torch.exp(logp[None] * (k * Tl)[:, None, None])
+            base, n = p.clone(), int(Tl)
+            step = torch.ones_like(p)                        # p^Tl by binary exponentiation
+            while n > 0:
+                if n & 1:
+                    step = step * base
+                base = base * base
+                n >>= 1
+            rows = [torch.ones_like(p)]
+            for _ in range(1, self.world):
+                rows.append(rows[-1] * step)
+            hit = torch.stack(rows, 0)
             if len(self._pow_cache) > 64:
                 self._pow_cache.clear()
             self._pow_cache[key] = hit
@@ -102,23 +197,47 @@ class SequenceParallelScorer:
         D, H = m.hidden_size, m.num_heads
         f = blk.filter
         n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
+        # (1) halo: the shard's last two rows go to the next rank.  They are projected on their own first (2B rows:
+        #     the weight-streaming kernel) so that the send/recv flies under the big projection GEMM.
+        halo, halo_w = None, _Done()
+        if self.world > 1:
+            if Tloc >= 2:
+                rows = n1.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D)
+                tail = ops.linear(rows, blk.projections.weight, blk.projections.bias).view(B, 2, 3 * D)
+            else:                                            # (last rank only, see check_geometry: nobody reads it)
+                tail = n1.new_zeros(B, 2, 3 * D)
+            halo, halo_w = self._shift(tail)
         z = ops.linear(n1, blk.projections.weight, blk.projections.bias).view(B, Tloc, 3 * D)
-        # (1) halo: every rank publishes its last two rows; rank r reads rank r-1's
-        tail = z[:, -2:, :] if Tloc >= 2 else torch.cat([z.new_zeros(B, 2 - Tloc, 3 * D), z], dim=1)
-        tails, _ = self._gather0(tail)
-        halo = tails[self.rank - 1].contiguous() if self.rank > 0 else None
-        # (2) shard end state from a zero carry-in, (3) exchange
-        st1, e_r = ops.hyena_stage1(z, f._fir_w, f.short_filter_bias, f._poles, H, z_halo=halo)
-        ends, _ = self._gather0(torch.view_as_real(e_r.to(torch.complex64)))
-        # (4) carry entering this shard
-        s0 = None
-        if self.rank > 0:
-            pw = self._pole_powers(f._poles, Tl)                               # [R, D, 8]
-            e = torch.view_as_complex(ends[: self.rank].double().contiguous())  # [r, B, D, 8]
-            idx = torch.arange(self.rank - 1, -1, -1, device=e.device)         # exponent index r-1-q
-            s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
-        # (5)
-        y = ops.hyena_stage2(z, f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1, z_halo=halo, s0=s0)
+        halo_w.wait()
+        if halo is not None:
+            halo = halo.contiguous()
+        # (2)-(5), pipelined over groups of batch rows
+        G = max(1, min(self.row_groups, B))
+        bounds = [(g * B) // G for g in range(G + 1)]
+        st1, ends, works = [None] * G, [None] * G, [None] * G
+        for g in range(G):
+            b0, b1 = bounds[g], bounds[g + 1]
+            hg = halo[b0:b1] if halo is not None else None
+            st1[g], e_r = ops.hyena_stage1(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, H, z_halo=hg)
+            ends[g], works[g] = self._gather0(torch.view_as_real(e_r.to(torch.complex64)), async_op=True,
+                                              name="state_allgather")
+        y = torch.empty(B, Tloc, D, dtype=z.dtype, device=z.device) if G > 1 else None
+        for g in range(G):
+            b0, b1 = bounds[g], bounds[g + 1]
+            works[g].wait()
+            s0 = None
+            if self.rank > 0:                                # (4) carry entering this shard
+                pw = self._pole_powers(f._poles, Tl)                               # [R, D, 8]
+                e = torch.view_as_complex(ends[g][: self.rank].double().contiguous())  # [r, b, D, 8]
+                idx = torch.arange(self.rank - 1, -1, -1, device=e.device)         # exponent index r-1-q
+                s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
+            hg = halo[b0:b1] if halo is not None else None
+            yg = ops.hyena_stage2(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1[g],
+                                  z_halo=hg, s0=s0)
+            if G > 1:
+                y[b0:b1] = yg
+            else:
+                y = yg
         ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
         m._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
 
@@ -144,24 +263,30 @@ class SequenceParallelScorer:
         fwd = []
         for b in range(B):                                   # [Tl, 3, R, Hr, hd] -> [R, Tl, 3, Hr, hd]: slice g -> rank g
             x = qkv[b].view(Tloc, 3, R, Hr, hd)
-            send = x.new_zeros(R, Tl, 3, Hr, hd)
-            send[:, :Tloc] = x.permute(2, 0, 1, 3, 4)
-            fwd.append(self.comm.all_to_all(send, async_op=True))
+            send = self._buf(("a2a_send", b), (R, Tl, 3, Hr, hd), qkv)     # reused by every attention layer
+            send[:, :Tloc].copy_(x.permute(2, 0, 1, 3, 4))
+            if Tloc < Tl:
+                send[:, Tloc:].zero_()                       # ragged last shard: the pad rows are never attended to
+            fwd.append(self._post("a2a_qkv", self.comm.all_to_all, send, async_op=True))
         back = []
         for b in range(B):
             recv, w = fwd[b]
             w.wait()
             full = recv.view(R * Tl, 3, Hr, hd)[None]        # the whole (padded) sequence, this rank's heads
             o = ops.attention(full[:, :T, 0], full[:, :T, 1], full[:, :T, 2], 0)           # [1, T, Hr, hd]
-            ret = o.new_zeros(R * Tl, Hr, hd)
-            ret[:T] = o[0]
-            back.append(self.comm.all_to_all(ret.view(R, Tl, Hr, hd), async_op=True))     # slice q -> token owner q
+            if R * Tl == T:
+                ret = o[0]
+            else:
+                ret = self._buf(("a2a_ret", b), (R * Tl, Hr, hd), o)
+                ret[:T].copy_(o[0])
+                ret[T:].zero_()
+            back.append(self._post("a2a_out", self.comm.all_to_all, ret.view(R, Tl, Hr, hd), async_op=True))
             fwd[b] = None
         a = torch.empty(B, Tloc, H, hd, dtype=qkv.dtype, device=qkv.device)
         for b in range(B):
             recv, w = back[b]
             w.wait()
-            a[b] = recv[:, :Tloc].permute(1, 0, 2, 3).reshape(Tloc, H, hd)                 # [R(head group), Tl, Hr, hd]
+            a[b].view(Tloc, R, Hr, hd).copy_(recv[:, :Tloc].permute(1, 0, 2, 3))          # [R(head group), Tl, Hr, hd]
         return a
 
     def _attn_allgather(self, qkv, B, Tloc, Tl, t0):
@@ -173,7 +298,7 @@ class SequenceParallelScorer:
             kv = qkv[b, :, 1:3]
             if Tloc < Tl:
                 kv = torch.cat([kv, kv.new_zeros(Tl - Tloc, 2, H, hd)], dim=0)
-            g, w = self._gather0(kv, async_op=True)
+            g, w = self._gather0(kv, async_op=True, name="kv_allgather")
             bufs.append(g)
             works.append(w)
         a = torch.empty(B, Tloc, H, hd, dtype=qkv.dtype, device=qkv.device)
@@ -192,10 +317,9 @@ class SequenceParallelScorer:
         if not m._packed:
             m._pack()
         B, T = ids_full.shape
+        self.check_geometry(T)                               # same verdict on every rank, before any collective
         Tl, t0, t1 = self.shard(T)
         Tloc = t1 - t0
-        if Tloc <= 0:
-            raise ValueError("sequence shorter than the number of ranks")
         ops = m.ops
         h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight)
         for blk in m.blocks:

@@ -1,0 +1,267 @@
+"""GPU (-m gpu): model-level parity at the REAL depth and width (32 layers, D = 4096, H = 32, inner 10928) on
+BASELINE configs, and operator-level cross-checks at the BASELINE sizes the CPU oracle cannot reach.
+
+What is compared with what (reference path: /root/reference/evo/scoring.py:80-84 -> model(input_ids)):
+
+ (a) BASELINE configs[0] (1 x 512 nt, T = 513), evo-1-8k AND evo-1-131k (rotary / 16) yml: the HIP engine vs
+     the CPU oracle in fp32 mode on the SAME synthetic 7B weights (bf16-rounded) and the same ids.
+     Metrics, pinned to ABSOLUTE numbers (tests/PARITY.md records the measured values they come from):
+       * score_rel   = |score_hip - score_oracle| / |score_oracle|   (north-star "1e-3 relative" -- met here)
+       * logits rel-L2 and max |delta| in units of a bf16 half-ulp at the row's scale
+     The bf16-faithful oracle (a rounding after every eager op = what upstream computes) is run beside it: the
+     engine must not be further from fp32 than that restatement is.
+ (b) prefix check at bench length: rows of the 8 x 8,193 HIP run (BASELINE configs[1]) vs the fp32 oracle on the
+     first 2,049 tokens of the same row -- causality makes them comparable.
+ (c) full-size operator checks against GPU restatements in fp64 (TEST INFRASTRUCTURE, rocFFT / eager matmul):
+     the Hyena operator vs an FFT long convolution at 8 x 8,193 x 4096 and 1 x 131,073 x 4096, and causal
+     attention vs eager softmax attention at H = 32, T = 8,193.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stripedhyena_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+FULL = dict(vocab_size=512, hidden_size=4096, num_layers=32, attn_layer_idxs=[8, 16, 24], num_attention_heads=32)
+FULL_131K = dict(FULL, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+
+
+def rel_l2(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).norm() / ref.norm()).item()
+
+
+def acgt_ids(B, L, seed=1234):
+    """SURVEY 8(d) inputs: default_rng(1234 + b).choice("ACGT"), BOS prepended."""
+    rows = []
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        rows.append(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L))
+    ids = torch.from_numpy(np.stack(rows).astype(np.int64))
+    return torch.cat([torch.zeros(B, 1, dtype=torch.long), ids], dim=1)
+
+
+def score_of(logits, ids):
+    lsm = torch.log_softmax(logits.double()[:, :-1], -1)
+    return lsm.gather(-1, ids[:, 1:, None].long()).squeeze(-1).mean(-1)
+
+
+def half_ulps(got, ref):
+    """max |got - ref| in units of half a bf16 ulp at the scale of the row (max(|ref|, rms of the row))."""
+    got, ref = got.double().cpu(), ref.double().cpu()
+    scale = torch.maximum(ref.abs(), ref.pow(2).mean(-1, keepdim=True).sqrt())
+    return ((got - ref).abs() / (scale * 2.0 ** -9)).max().item()
+
+
+@pytest.fixture(scope="module")
+def full():
+    """One synthetic 7B state dict (built on the GPU, 12.9 GB), the HIP models of both yml configs sharing it, and
+    the fp32 / bf16-faithful CPU oracles on a host copy."""
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.synthetic import synthetic_state_dict
+    t0 = time.time()
+    m8 = StripedHyena(dict(FULL))
+    sd = synthetic_state_dict(m8, seed=0, device=DEV)
+    m8.load_state_dict(sd, strict=True)
+    m8.to_bfloat16_except_poles_residues()
+    m8 = m8.to(DEV)
+    m131 = StripedHyena(dict(FULL_131K))
+    m131.load_state_dict(m8.state_dict(), strict=True)       # adopts the same (already packed) tensors
+    m131.to_bfloat16_except_poles_residues()
+    m131 = m131.to(DEV)
+    sd_cpu = {k: v.cpu() for k, v in m8.state_dict().items()}
+    print(f"[full-depth fixture] weights in {time.time() - t0:.1f} s; host MemAvailable {_host_mem_gb():.0f} GB, "
+          f"{os.cpu_count()} cpus, torch threads {torch.get_num_threads()}")
+    return dict(m8=m8, m131=m131, sd_cpu=sd_cpu, oracles={})
+
+
+def _host_mem_gb():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            return int(line.split()[1]) / 1e6
+    return 0.0
+
+
+def oracle_for(full, cfgd, mode):
+    """One oracle object per numeric mode (fp32: 26 GB of up-cast weights, bf16: aliases the host copy); the two yml
+    configs differ only in the rotary table, which the oracle derives from `cfg` on every call."""
+    if mode not in full["oracles"]:
+        need = 34.0 if mode == "fp32" else 4.0
+        if _host_mem_gb() < need:
+            pytest.skip(f"host has {_host_mem_gb():.0f} GB available; the {mode} full-depth oracle needs {need:.0f} GB")
+        full["oracles"][mode] = R.RefStripedHyena(R.RefConfig.from_dict(cfgd), full["sd_cpu"], mode)
+    o = full["oracles"][mode]
+    o.cfg = R.RefConfig.from_dict(cfgd)
+    return o
+
+
+# ---- (a) pinned numbers, measured on MI355X in round 2 (see tests/PARITY.md); asserted with ~1.5x headroom ---------
+PIN_A = {          # yml        score_rel  rel-L2   half-ulps
+    "8k": dict(score=1.0e-3, rl2=2.0e-2, hulp=40.0),
+    "131k": dict(score=1.0e-3, rl2=2.0e-2, hulp=40.0),
+}
+
+
+@pytest.mark.parametrize("name", ["8k", "131k"])
+def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
+    cfgd = FULL if name == "8k" else FULL_131K
+    m = full["m8"] if name == "8k" else full["m131"]
+    ids = acgt_ids(1, 512)
+    t0 = time.time()
+    ref = oracle_for(full, cfgd, "fp32")(ids)[0]
+    t_cpu = time.time() - t0
+    floor_logits = oracle_for(full, cfgd, "bf16")(ids)[0]
+    logits = m(ids.to(DEV))[0]
+    assert logits.shape == ref.shape == (1, 513, 512) and logits.dtype == torch.bfloat16
+    assert ref.std() > 0.1                                    # non-degenerate logits
+    err, floor = rel_l2(logits, ref), rel_l2(floor_logits, ref)
+    hu, hu_floor = half_ulps(logits, ref), half_ulps(floor_logits, ref)
+    s_hip, s_ref, s_floor = (score_of(x.cpu(), ids).item() for x in (logits, ref, floor_logits))
+    srel, srel_floor = abs(s_hip - s_ref) / abs(s_ref), abs(s_floor - s_ref) / abs(s_ref)
+    print(f"[full-depth {name}] oracle fp32 pass {t_cpu:.1f} s ({512 / t_cpu:.0f} nt/s on {torch.get_num_threads()} threads)")
+    print(f"[full-depth {name}] logits rel-L2 hip={err:.3e} (bf16-faithful oracle {floor:.3e}); "
+          f"half-ulps hip={hu:.1f} (oracle-bf16 {hu_floor:.1f}); score hip={s_hip:.6f} fp32={s_ref:.6f} "
+          f"rel={srel:.2e} (oracle-bf16 {srel_floor:.2e})")
+    pin = PIN_A[name]
+    assert srel <= pin["score"]
+    assert err <= pin["rl2"] and hu <= pin["hulp"]
+    assert err <= 1.25 * floor                                # never further from fp32 than eager bf16 is
+
+
+def test_prefix_of_bench_batch_vs_fp32_oracle(full):
+    """BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
+    oracle run on that prefix alone (the model is causal)."""
+    P = 2049
+    ids = acgt_ids(8, 8192)
+    logits = full["m8"](ids.to(DEV))[0]
+    assert logits.shape == (8, 8193, 512)
+    t0 = time.time()
+    ref = oracle_for(full, FULL, "fp32")(ids[3:4, :P])[0]
+    print(f"[prefix] oracle fp32 on {P} tokens: {time.time() - t0:.1f} s")
+    got = logits[3:4, :P]
+    err, hu = rel_l2(got, ref), half_ulps(got, ref)
+    s_hip, s_ref = score_of(got.cpu(), ids[3:4, :P]).item(), score_of(ref, ids[3:4, :P]).item()
+    srel = abs(s_hip - s_ref) / abs(s_ref)
+    print(f"[prefix] logits rel-L2 {err:.3e}, half-ulps {hu:.1f}, score rel {srel:.2e}")
+    assert srel <= 1.0e-3 and err <= 2.0e-2 and hu <= 48.0
+    # and the batch row must not depend on its neighbours: row 3 alone == row 3 of the batch (bit-identical kernels)
+    alone = full["m8"](ids[3:4].to(DEV))[0]
+    assert rel_l2(alone[:, :P], got) < 2e-2
+
+
+# ---- (c) full-size operator cross-checks -------------------------------------------------------------------------
+def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128):
+    """TEST INFRASTRUCTURE.  fp64 GPU restatement of oracle.op_hyena (FIR + split + x1*v + FFT long convolution +
+    gate) on device tensors, evaluated per batch row in chunks of `chunk` channels of one head so that the
+    complex128 FFT buffers stay ~1 GB.  Returns y [B,T,D] float64 (on device) and the end state [B,D,8] c128."""
+    B, T, D3 = z.shape
+    D = D3 // 3
+    hd = D // H
+    n = 1 << int(math.ceil(math.log2(2 * T - 1)))               # any n >= 2T-1 gives the same linear convolution
+    y = torch.empty(B, T, D, dtype=torch.float64, device=z.device)
+    st = torch.empty(B, D, 8, dtype=torch.complex128, device=z.device)
+    t = torch.arange(T, dtype=torch.float64, device=z.device)
+    w = fir_w.double()
+    for h in range(H):
+        for c0 in range(0, hd, chunk):
+            cs = slice(c0, c0 + chunk)
+            dsl = slice(h * hd + c0, h * hd + c0 + chunk)
+            p = torch.view_as_complex(poles[dsl].double().contiguous())
+            r = torch.view_as_complex(residues[dsl].double().contiguous())
+            pw = torch.exp(torch.log(p)[..., None] * t)                         # [c,8,T]
+            hf = torch.fft.rfft((r[..., None] * pw).real.sum(1), n=n)           # [c, n/2+1]
+            for b in range(B):
+                f = []
+                for g in range(3):
+                    col = slice(h * 3 * hd + g * hd + c0, h * 3 * hd + g * hd + c0 + chunk)
+                    zz = torch.nn.functional.pad(z[b, :, col].double().t(), (2, 0))      # [c, T+2]
+                    wc = w[col]
+                    f.append(wc[:, 0:1] * zz[:, 0:T] + wc[:, 1:2] * zz[:, 1:T + 1] + wc[:, 2:3] * zz[:, 2:T + 2]
+                             + fir_b[col].double()[:, None])
+                x2, x1, v = f
+                x1v = x1 * v
+                conv = torch.fft.irfft(torch.fft.rfft(x1v, n=n) * hf, n=n)[:, :T]
+                y[b, :, dsl] = ((conv + x1v * dskip[dsl].double()[:, None]) * x2).t()
+                st[b, dsl] = torch.einsum("ct,cst->cs", x1v.to(torch.complex128), pw.flip(-1))
+                del f, x2, x1, v, x1v, conv
+            del pw, hf
+    return y, st
+
+
+def _hyena_inputs(B, T, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    D, H = 4096, 32
+    z = torch.randn(B, T, 3 * D, generator=g, device=DEV).bfloat16()
+    fir_w = (torch.randn(3 * D, 3, generator=g, device=DEV) * 0.3).bfloat16()
+    fir_b = (torch.randn(3 * D, generator=g, device=DEV) * 0.1).bfloat16()
+    one_minus = 10.0 ** (-5.0 + 4.0 * torch.rand(D, 8, generator=g, device=DEV))
+    mag = 1.0 - one_minus
+    ang = (torch.rand(D, 8, generator=g, device=DEV) * 2 - 1) * math.pi
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous()
+    res = (torch.randn(D, 8, 2, generator=g, device=DEV) * torch.sqrt(one_minus).unsqueeze(-1)).float().contiguous()
+    dskip = (torch.randn(D, generator=g, device=DEV) * 0.5).bfloat16()
+    return z, (fir_w, fir_b, poles, res, dskip, H)
+
+
+def _check_hyena_fullsize(B, T, seed, state_tol):
+    from evo_amd.ops import HipOps
+    ops = HipOps()
+    z, prm = _hyena_inputs(B, T, seed)
+    y, st = ops.hyena_prefill(z, *prm, want_state=True)
+    t0 = time.time()
+    ry, rst = gpu_fft_hyena(z, *prm)
+    torch.cuda.synchronize()
+    print(f"[fft cross-check {B}x{T}] fp64 rocFFT restatement: {time.time() - t0:.1f} s")
+    yd = y.double()
+    err = (yd - ry).abs()
+    bound = ry.abs() * 2 ** -8 + float(ry.abs().max()) * 2e-3
+    rl2 = ((yd - ry).norm() / ry.norm()).item()
+    srel = ((st.to(torch.complex128) - rst).abs().max() / rst.abs().max()).item()
+    print(f"[fft cross-check {B}x{T}] y rel-L2 {rl2:.3e}, worst excess over the bf16 bound "
+          f"{(err - bound).max().item():.3e}, end-state rel {srel:.2e}")
+    assert torch.isfinite(yd).all()
+    assert (err <= bound).all()
+    assert rl2 < 2e-3                                           # one bf16 output rounding = 1.1e-3
+    assert srel <= state_tol
+
+
+def test_hyena_operator_8x8193_full_width_vs_fft():
+    """BASELINE configs[1] shape of one Hyena layer: every one of the 8 x 8,193 x 4096 outputs vs the FFT form."""
+    _check_hyena_fullsize(8, 8193, 21, 2e-5)
+
+
+def test_hyena_operator_1x131073_full_width_vs_fft():
+    """BASELINE configs[2] shape: T = 131,073 at all 4096 channels, |p| up to 0.99999."""
+    _check_hyena_fullsize(1, 131073, 22, 1e-4)
+
+
+def test_attention_h32_t8193_vs_eager_fp64():
+    """BASELINE configs[1] attention shape (one batch row, all 32 heads, T = 8,193) vs eager softmax attention in
+    fp64 on the GPU (TEST INFRASTRUCTURE; FlashAttention-2 numerics tolerance: P is rounded to bf16)."""
+    from evo_amd.ops import HipOps
+    ops = HipOps()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    T, H = 8193, 32
+    qkv = torch.randn(1, T, 3, H, 128, generator=g, device=DEV).bfloat16()
+    o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+    mask = torch.ones(T, T, dtype=torch.bool, device=DEV).triu(1)
+    worst_rl2, worst_abs = 0.0, 0.0
+    for h in range(H):
+        q, k, v = (qkv[0, :, i, h].double() for i in range(3))
+        sc = (q @ k.t()) / math.sqrt(128.0)
+        sc.masked_fill_(mask, float("-inf"))
+        ref = torch.softmax(sc, -1) @ v
+        got = o[0, :, h].double()
+        worst_rl2 = max(worst_rl2, ((got - ref).norm() / ref.norm()).item())
+        worst_abs = max(worst_abs, ((got - ref).abs() - ref.abs() * 2 ** -7).max().item())
+        del sc, ref
+    print(f"[attention H=32 T=8193] worst head rel-L2 {worst_rl2:.3e}, worst |err| - 2^-7|ref| = {worst_abs:.3e}")
+    assert worst_rl2 < 4e-3
+    assert worst_abs < 2e-2

@@ -72,3 +72,41 @@ def test_sequence_parallel_matches_unsharded(world, T, B, attn_mode):
     assert covered[0][0] == 0 and covered[-1][1] == T
     for _, _, _, e_logits, e_lp in res:
         assert e_logits < 1e-9 and e_lp < 1e-5
+
+
+def test_shard_geometry_verdict_is_rank_independent():
+    """(world-1)*ceil(T/world) >= T leaves an empty shard (e.g. T = 9, R = 4) -- every rank must raise
+    BEFORE the first collective, not only the empty one (the others would hang in all_gather)."""
+    from evo_amd.sp import SequenceParallelScorer
+
+    class _NoComm:
+        world = 4
+
+    for T, world, ok in [(9, 4, False), (10, 4, True), (3, 4, False), (4, 4, False), (8, 4, True), (131073, 8, True)]:
+        verdicts = []
+        for r in range(world):
+            sp = SequenceParallelScorer(None, r, world, comm=_NoComm())
+            try:
+                sp.check_geometry(T)
+                verdicts.append(True)
+            except ValueError:
+                verdicts.append(False)
+        assert verdicts == [ok] * world, (T, world, verdicts)
+
+
+def test_pole_powers_integer_exponentiation():
+    """p^(Tl*k) in fp64 by repeated squaring: exact 1 at k = 0 even for a zero pole (log(0)*0 was NaN)."""
+    from evo_amd.sp import SequenceParallelScorer
+
+    class _NoComm:
+        world = 3
+
+    sp = SequenceParallelScorer(None, 1, 3, comm=_NoComm())
+    poles = torch.tensor([[[0.0, 0.0], [0.5, 0.5]], [[0.99999, 0.0], [-0.3, 0.9]]], dtype=torch.float32)
+    pw = sp._pole_powers(poles, 1000)
+    assert pw.shape == (3, 2, 2) and torch.isfinite(torch.view_as_real(pw)).all()
+    p = torch.view_as_complex(poles.double())
+    assert torch.equal(pw[0], torch.ones_like(p))
+    want1 = torch.where(p == 0, torch.zeros_like(p), torch.exp(torch.log(torch.where(p == 0, torch.ones_like(p), p)) * 1000))
+    assert (pw[1] - want1).abs().max() < 1e-12
+    assert (pw[2] - want1 * want1).abs().max() < 1e-12
