@@ -51,13 +51,16 @@ def build_model(name, device, seed=0):
 
 
 def scoring_step(model, ids):
-    """forward + per-token log-prob of the next token (what evo.scoring.score_sequences computes on device)."""
-    from evo_amd.scoring import logits_to_logprobs
-    logits, _ = model(ids)
-    return logits_to_logprobs(logits, ids, trim_bos=True)
+    """forward + per-token log-prob of the next token: exactly what evo_amd.score_sequences runs on the device
+    (32 blocks, final norm, fused unembed + log-softmax + gather)."""
+    from evo_amd.scoring import score_logprobs_device
+    return score_logprobs_device(model, ids)[0]
 
 
-def timed(fn, steps, warmup, dist_on):
+def timed(fn, steps, warmup, dist_on, stats=None):
+    """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; wall clock, MAX
+    over ranks (the contract).  Beside it, a HIP event is recorded on the launch stream at every step boundary:
+    `stats` receives the per-step device durations (median / min / max) -- SURVEY 8(d) asks for hipEvent medians."""
     import torch.distributed as dist
     for _ in range(warmup):
         fn()
@@ -65,9 +68,12 @@ def timed(fn, steps, warmup, dist_on):
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         fn()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -77,6 +83,11 @@ def timed(fn, steps, warmup, dist_on):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if stats is not None:
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        stats.update({"hip_event_ms_median": per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]),
+                      "hip_event_ms_min": per[0], "hip_event_ms_max": per[-1],
+                      "wall_ms_mean": dt / steps * 1e3})
     return dt
 
 
@@ -96,21 +107,48 @@ def flops_per_token(T):
     return 32 * 402_784_256 + 2 * 4096 * 512 + 24_576 * T
 
 
-def cpu_baseline(nt=512, layers=(0, 1, 2, 3)):
-    """The oracle (a 'port' of the reference forward) on the host cores: a 4-block slice (3 Hyena + 1 attention)
-    at full width on one 512-nt sequence, scaled x8 to the 32-block depth.  fp32 mode (the same bf16-rounded
-    weights up-cast to fp32, MKL sgemm): torch's CPU bf16 path was slower still on the GPU box's EPYC host, so
-    this choice FAVOURS the CPU."""
+def _host_mem_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(model=None, nt=512):
+    """The oracle (a 'port' of the reference forward: its eager-attention CPU path) on the host cores, BASELINE
+    configs[0]: the FULL 32-block evo-1-8k-base forward on one 512-nt sequence, on the very weights the GPU run
+    used (copied to the host).  fp32 mode (bf16-rounded weights up-cast to fp32, MKL sgemm): torch's CPU bf16 path
+    was slower still on the GPU box's host, so this choice FAVOURS the CPU.  One untimed short pass warms the
+    thread pools, then one timed full pass (~10 s).  Falls back to a 4-of-32-block slice (x8) only when the host
+    has no room for the 39 GB of host weights."""
     from oracle import stripedhyena_ref as R
-    # 32 threads: with all 256 hardware threads of the GPU box's host the same slice took 65 s (oversubscribed
-    # small ops) against ~2 s on 8 threads elsewhere; `cores` reports what was actually used
+    # 32 threads: with all 256 hardware threads of the GPU box's host the same work took 30x longer (oversubscribed
+    # small ops); `cores` reports what was actually used
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ids = acgt_ids(1, nt, 1234, "cpu")
+    if model is not None and _host_mem_gb() > 60.0:
+        cfg = R.RefConfig()                                  # evo-1-8k-base dims (the dataclass defaults)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        m = R.RefStripedHyena(cfg, sd, "fp32")
+        del sd
+        with torch.inference_mode():
+            m(ids[:, :33])                                   # warm-up (thread pools, oneDNN primitives)
+            t0 = time.perf_counter()
+            logits = m(ids)[0]
+            dt = time.perf_counter() - t0
+        lsm = torch.log_softmax(logits.double()[0, :-1], -1)
+        score = lsm.gather(-1, ids[0, 1:, None]).mean().item()
+        return {"value": nt / dt, "unit": "nt/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle fp32 mode (bf16-rounded weights), the full 32-block evo-1-8k-base forward on 1 x {nt} nt "
+                          f"(BASELINE configs[0]), one timed pass", "seconds": dt, "score": score}
     cfg = R.RefConfig(num_layers=4, attn_layer_idxs=(2,))
     sd = R.make_synthetic_state_dict(cfg, 0)
     m = R.RefStripedHyena(cfg, sd, "fp32")
-    ids = acgt_ids(1, nt, 1234, "cpu")
     with torch.inference_mode():
-        m(ids)                                           # warm-up (thread pools, oneDNN primitives)
+        m(ids)
         t0 = time.perf_counter()
         reps = 0
         while reps < 12 and time.perf_counter() - t0 < 20.0:
@@ -120,7 +158,28 @@ def cpu_baseline(nt=512, layers=(0, 1, 2, 3)):
     full = dt * (32 / 4)
     return {"value": nt / full, "unit": "nt/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle fp32 mode (bf16-rounded weights), 4 of 32 blocks (3 Hyena + 1 attention) at D=4096, 1 x {nt} nt, "
-                      f"{reps} reps, time x8 for full depth", "seconds_per_4_blocks": dt}
+                      f"{reps} reps, time x8 for full depth (host memory too small for the full-depth copy)",
+            "seconds_per_4_blocks": dt}
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script under torch.distributed.run,
+    one per GPU, and pass their exit code on.  Fails loudly when the box has fewer than N devices."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible "
+                         f"(torch.cuda.device_count()); refusing to benchmark fewer GPUs than asked for\n")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -137,15 +196,24 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args.gpus)                 # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
+    if torch.cuda.device_count() <= local:
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local}, {torch.cuda.device_count()} visible)\n")
+        sys.exit(2)
     dist_on = world > 1
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
+        assert dist.get_world_size() == world
     n_gpus = world
 
     from evo_amd.ops import KernelTimer, default_ops
@@ -156,8 +224,9 @@ def main():
     B, nt = args.batch, args.nt
     ids = acgt_ids(B, nt, 1234 + 1000 * rank, device)
     T = nt + 1
+    step_stats = {}
     with torch.inference_mode():
-        dt = timed(lambda: scoring_step(model, ids), args.steps, args.warmup, dist_on)
+        dt = timed(lambda: scoring_step(model, ids), args.steps, args.warmup, dist_on, step_stats)
         # per-kernel HIP-event timings over a second, separately instrumented pass of the same steps
         ops.timer = KernelTimer()
         for _ in range(args.steps):
@@ -176,6 +245,8 @@ def main():
     roofline = {"kernel": "hyena_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("hyena_apply_kernel", B, T),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
+                # live sanity figure: bytes of the tensors the launch actually touched (z in, y out, entering states)
+                "tensor_bytes_per_launch": getattr(ops, "last_hyena_io", {}).get("apply"),
                 "operator_3_launch_ms": op_ms, "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     attn_flops = B * 4 * D * T * T / 2                    # causal QK^T + PV per layer
     kernels = {k: {"launches_per_step": v[0] // args.steps, "avg_ms": v[1]} for k, v in ksum.items()}
@@ -186,12 +257,25 @@ def main():
         "metric": "nucleotides/sec forward scoring, evo-1 7B", "value": value, "unit": "nt/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic ACGT, synthetic weights",
+        "n_ranks": dist.get_world_size() if dist_on else 1,
+        "collectives": ("RCCL %s (torch.distributed backend nccl)" % ".".join(map(str, torch.cuda.nccl.version()))) if dist_on else None,
+        "step_timing": step_stats,
         "config": {"workload": "evo-1-8k-base scoring, batch 8 x 8,192 nt per GPU (BASELINE configs[1])",
                    "batch_per_gpu": B, "nt": nt, "tokens_per_seq": T,
                    "parallelism": "independent batches per GPU" if n_gpus > 1 else "single GPU"},
         "model_tflops": flops_per_token(T) * B * T / (dt / args.steps) / 1e12,
         "roofline": roofline, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
     }
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and n_gpus == 1 and not args.skip_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(model)
+            with torch.inference_mode():                  # the same sequence on the GPU engine: scores must agree
+                ids0 = acgt_ids(1, 512, 1234, device)
+                lp0 = scoring_step(model, ids0)
+            out["cpu_baseline"]["gpu_score_same_input"] = float(lp0.double().mean().item())
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     del model
     torch.cuda.empty_cache()
 
@@ -209,25 +293,25 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["generation"] = {"error": f"{type(e).__name__}: {e}"}
 
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
-    if rank == 0 and n_gpus == 1 and not args.skip_cpu:
-        out["cpu_baseline"] = cpu_baseline()
+    if n_gpus > 1 and "ctx131k" in out and "error" not in out["ctx131k"]:
+        out["scaling_131k"] = out["ctx131k"].get("scaling")   # BASELINE configs[3]: the sequence-split result, top level
     if rank == 0:
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
 
 
-def bench_generation(device, prompt=8192, new=256):
-    """evo-1-131k-base, 8,192-nt prompt -> `new` greedy tokens, batch 1: full-prompt parallel prefill (exact carried
-    Hyena state + KV cache), then the recurrent decode step (hipGraph-captured, weight-streaming GEMV)."""
+def bench_generation(device, prompt=8192, new=1024):
+    """BASELINE configs[4]: evo-1-131k-base, 8,192-nt prompt -> 1,024 new tokens, batch 1: full-prompt parallel prefill
+    (exact carried Hyena state + KV cache), then the recurrent decode step (hipGraph-captured, weight-streaming
+    GEMV).  Greedy (top_k = 1, deterministic) is the headline; the reference CLI's sampling profile (top_k = 4,
+    temperature 1.0 [REF scripts/generate.py:28-30]) is timed beside it."""
     from evo_amd.generation import Generator
     from evo_amd.tokenizer import CharLevelTokenizer
     model = build_model("evo-1-131k-base", device)
     ids = acgt_ids(1, prompt, 777, device)[:, 1:]                    # no BOS: generate()'s default
-    g = Generator(model, CharLevelTokenizer(512), top_k=1, top_p=1.0, temperature=1.0)
 
-    def run(n):
+    def run(g, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         g.generate(device=device, input_ids=ids, num_tokens=n, cached_generation=True, print_generation=False,
@@ -235,14 +319,20 @@ def bench_generation(device, prompt=8192, new=256):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    run(3)
-    t_pre = min(run(1) for _ in range(2))
-    t_all = run(1 + new)
+    g1 = Generator(model, CharLevelTokenizer(512), top_k=1, top_p=1.0, temperature=1.0)
+    run(g1, 3)
+    t_pre = min(run(g1, 1) for _ in range(2))
+    t_all = run(g1, 1 + new)
     dec = (t_all - t_pre) / new
-    res = {"config": {"workload": f"evo-1-131k-base generation, {prompt}-nt prompt -> {new} new tokens, batch 1, greedy"},
+    g4 = Generator(model, CharLevelTokenizer(512), top_k=4, top_p=1.0, temperature=1.0)
+    run(g4, 3)
+    dec4 = (run(g4, 1 + new) - t_pre) / new
+    res = {"config": {"workload": f"evo-1-131k-base generation, {prompt}-nt prompt -> {new} new tokens, batch 1, greedy "
+                                  f"(BASELINE configs[4])"},
            "prefill_ms": t_pre * 1e3, "prefill_nt_per_s": prompt / t_pre, "decode_ms_per_token": dec * 1e3,
-           "decode_tokens_per_s": 1.0 / dec,
+           "decode_tokens_per_s": 1.0 / dec, "end_to_end_s": t_all,
            "weight_stream_GBps": 12.906 / dec, "hbm_frac": 12.906e9 / dec / 1e9 / HBM_PEAK_GBS,
+           "top_k4_decode_ms_per_token": dec4 * 1e3,
            "graph_engaged": getattr(model, "_dgraph", None) is not None}
     del model
     torch.cuda.empty_cache()
@@ -250,37 +340,62 @@ def bench_generation(device, prompt=8192, new=256):
 
 
 def bench_131k(args, device, rank, world, dist_on, ops):
+    """BASELINE configs[2] (world 1: batch 1 x 131,072 nt on one GPU) / configs[3] (world N: batch N, the SEQUENCE
+    dimension sharded over the N ranks, evo_amd/sp.py).  For N > 1 every rank also times the single-GPU batch-1 pass
+    in the same job, so the speed-up of the sequence split is an in-run ratio of nt/s."""
+    import torch.distributed as dist
     from evo_amd.ops import KernelTimer
     model = build_model("evo-1-131k-base", device)
     nt = 131072
     T = nt + 1
+    ids1 = acgt_ids(1, nt, 4321, device)
+    single = lambda: scoring_step(model, ids1)            # noqa: E731
+    scaling = None
     if world == 1:
-        ids = acgt_ids(1, nt, 4321, device)
-        fn = lambda: scoring_step(model, ids)             # noqa: E731
-        B = 1
-        par = "single GPU"
+        fn, B, par = single, 1, "single GPU"
     else:
         from evo_amd.sp import SequenceParallelScorer
         B = world
         ids = acgt_ids(B, nt, 4321, device)               # every rank builds the same batch, keeps its shard
         scorer = SequenceParallelScorer(model, rank, world)
         fn = lambda: scorer.score_logprobs(ids)           # noqa: E731
-        par = f"sequence-parallel over {world} ranks (RCCL all-gather of states and K/V)"
+        par = f"sequence-parallel over {world} ranks (RCCL: neighbour halo send/recv, end-state all-gather, " \
+              f"head<->sequence all-to-all)"
+    st = {}
     with torch.inference_mode():
-        dt = timed(fn, args.steps_131k, 1, dist_on)
+        dt = timed(fn, args.steps_131k, 1, dist_on, st)
         ops.timer = KernelTimer()
         fn()
         torch.cuda.synchronize()
         ks = ops.timer.summary()
         ops.timer = None
+        if world > 1:
+            dt1 = timed(single, args.steps_131k, 1, dist_on)              # the same job's 1-GPU reference (replicas)
+            scorer.comm_profile = True                                    # raw duration of every exchange, serialised
+            fn()
+            torch.cuda.synchronize()
+            comm = scorer.comm_summary()
+            scorer.comm_profile = False
+            per1 = dt1 / args.steps_131k
+            per_layer = {k: {"count_per_step": v[0], "mean_ms": v[1]} for k, v in comm.items()}
+            scaling = {"workload": f"evo-1-131k-base scoring, batch {B} x 131,072 nt, sequence split over {world} ranks "
+                                   f"(BASELINE configs[3] at N = 8)",
+                       "n_ranks": dist.get_world_size(), "value": B * nt / (dt / args.steps_131k), "unit": "nt/s",
+                       "single_gpu_value_same_job": nt / per1, "speedup_vs_single_gpu": (B * nt / (dt / args.steps_131k)) / (nt / per1),
+                       "collectives_serialised_ms": per_layer,
+                       "collective_ms_per_step_serialised": sum(v[0] * v[1] for v in comm.values())}
     per = dt / args.steps_131k
     D = 4096
     Tl = T if world == 1 else (T + world - 1) // world
     alg_bytes = B * Tl * (3 * D * 2 + D * 2)
     apply_ms = ks["hyena_apply"][1]
     op_ms = apply_ms + ks["hyena_seg_state"][1] + ks["hyena_carry_scan"][1]
+    if world > 1:                                         # the row-group pipeline launches the operator per group
+        n_layers = 29
+        alg_bytes = alg_bytes * n_layers // ks["hyena_apply"][0]
     res = {"value": B * nt / per, "unit": "nt/s", "ms_per_step": per * 1e3, "steps": args.steps_131k,
            "config": {"workload": f"evo-1-131k-base scoring, batch {B} x 131,072 nt", "parallelism": par},
+           "step_timing": st,
            "model_tflops": flops_per_token(T) * B * T / per / 1e12,
            "roofline": {"kernel": "hyena_apply_kernel", "bound": "hbm",
                         "achieved": alg_bytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -290,6 +405,8 @@ def bench_131k(args, device, rank, world, dist_on, ops):
                         "operator_3_launch_ms": op_ms,
                         "operator_frac": alg_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "kernels": {k: {"launches": v[0], "avg_ms": v[1]} for k, v in ks.items()}}
+    if scaling is not None:
+        res["scaling"] = scaling
     if world == 1 and "attn_fwd" in ks:
         fl = 4 * D * T * T / 2
         res["kernels"]["attn_fwd"]["tflops"] = fl / (ks["attn_fwd"][1] * 1e-3) / 1e12

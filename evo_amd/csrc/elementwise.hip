@@ -5,26 +5,35 @@
 #include "../../include/evo_mi355x.h"
 
 // ------------------------------------------------------------------------------------------- embed
+// An id outside [0, vocab) never indexes the table: its row is written as zeros and *bad_flag (if given) is set, so
+// the host can raise where the reference's F.embedding would device-assert.
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const uint4* __restrict__ w,
-                                                    uint4* __restrict__ out, int64_t n_tok, int nvec) {
+                                                    uint4* __restrict__ out, int64_t n_tok, int nvec, int64_t vocab,
+                                                    int* __restrict__ bad_flag) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = n_tok * nvec;
     for (; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t tok = i / nvec;
         int c = (int)(i - tok * nvec);
-        out[i] = w[ids[tok] * nvec + c];
+        const int64_t id = ids[tok];
+        if (id >= 0 && id < vocab) {
+            out[i] = w[id * nvec + c];
+        } else {
+            out[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (bad_flag && c == 0) *bad_flag = 1;
+        }
     }
 }
 
 extern "C" int evo_embed_bf16(const int64_t* ids, const void* weight, void* out, int64_t n_tok, int64_t D,
-                              int64_t vocab, void* stream) {
+                              int64_t vocab, int* bad_flag, void* stream) {
     if (D % 8 != 0 || n_tok < 0 || vocab <= 0) return -1;
     if (n_tok == 0) return 0;
     int nvec = (int)(D / 8);
     int64_t total = n_tok * nvec;
     int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(embed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const uint4*)weight,
-                       (uint4*)out, n_tok, nvec);
+                       (uint4*)out, n_tok, nvec, vocab, bad_flag);
     return evo_launch_status();
 }
 
@@ -301,4 +310,4 @@ extern "C" int evo_logprob_entropy(const void* logits, int64_t logits_f32, const
     return evo_launch_status();
 }
 
-extern "C" int evo_abi_version(void) { return 1; }
+extern "C" int evo_abi_version(void) { return EVO_ABI_VERSION; }

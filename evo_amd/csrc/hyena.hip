@@ -24,7 +24,16 @@
 #define NS 8            // state_size   [REF evo/configs/evo-1-8k-base_inference.yml:14]
 #define HD 128          // channels per head (hidden_size / num_attention_heads)  [REF yml:2,9]
 #define CH 4            // rows (time steps) per DMA chunk
-#define NSLOT 6         // ring depth in chunks: NSLOT-1 chunks are in flight while one is consumed
+#ifndef HY_NSLOT
+#define HY_NSLOT 6
+#endif
+#define NSLOT HY_NSLOT  // ring depth in chunks: NSLOT-1 chunks are in flight while one is consumed
+#ifndef HY_VARIANT
+#define HY_VARIANT 1    // 0: round-1 instruction order (dependent pairs back to back); 1: mode-parallel phases
+#endif
+#ifndef HY_OCC
+#define HY_OCC 2        // waves per SIMD the register allocation is bounded for
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* glb_ptr_t;
@@ -97,12 +106,26 @@ struct ChunkMap {
 // outstanding as were issued after chunk c's DMA".  In the steady state that is, per ring stage, NDMA DMA
 // instructions plus the y stores of one chunk (apply: 4; seg_state: 0), times NSLOT-1 stages.  Counting the
 // stores matters: waiting them out too (vmcnt(15)) stalled every chunk on the ~2 us store latency.
-#define HY_WAIT_STATE() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")   /* 2 DMA x 5 stages            */
-#define HY_WAIT_APPLY() asm volatile("s_waitcnt vmcnt(35)" ::: "memory")   /* (3 DMA + 4 stores) x 5 stages */
-static_assert(NSLOT == 6 && CH == 4, "HY_WAIT_* immediates assume 5 stages in flight and 4 stores per chunk");
+#define HY_STR2(x) #x
+#define HY_STR(x) HY_STR2(x)
+#define HY_WAIT_STATE() asm volatile("s_waitcnt vmcnt(" HY_STR(HY_VM_STATE) ")" ::: "memory")   /* 2 DMA x (NSLOT-1) stages            */
+#define HY_WAIT_APPLY() asm volatile("s_waitcnt vmcnt(" HY_STR(HY_VM_APPLY) ")" ::: "memory")   /* (3 DMA + 4 stores) x (NSLOT-1) stages */
+#if HY_NSLOT == 6
+#define HY_VM_STATE 10
+#define HY_VM_APPLY 35
+#elif HY_NSLOT == 5
+#define HY_VM_STATE 8
+#define HY_VM_APPLY 28
+#elif HY_NSLOT == 4
+#define HY_VM_STATE 6
+#define HY_VM_APPLY 21
+#else
+#error "HY_NSLOT must be 4, 5 or 6 (the vmcnt immediates are tabulated)"
+#endif
+static_assert(CH == 4, "HY_WAIT_* immediates assume 4 stores per chunk");
 
 // ------------------------------------------------------------------------------------------------ launch 1
-__global__ __launch_bounds__(256, 2) void hyena_seg_state_kernel(
+__global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
     const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, float* __restrict__ agg, int B, int64_t T,
     int D, int H, int C, int n_seg) {
@@ -158,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void hyena_seg_state_kernel(
         const f32x2_t x1c = pk_fma(fc.w[1][2], c0, pk_fma(fc.w[1][1], m1[0], pk_fma(fc.w[1][0], m2[0], fc.b[1])));
         const f32x2_t vc = pk_fma(fc.w[2][2], c1, pk_fma(fc.w[2][1], m1[1], pk_fma(fc.w[2][0], m2[1], fc.b[2])));
         const f32x2_t x = x1c * vc;
+#if HY_VARIANT == 0
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const f32x2_t nr = pk_fma(pr[s], sr[s], pk_fma(-pi[s], si[s], x));
@@ -165,6 +189,20 @@ __global__ __launch_bounds__(256, 2) void hyena_seg_state_kernel(
             sr[s] = nr;
             si[s] = ni;
         }
+#else
+        // the 8 modes are independent: issue each stage of the complex multiply-add for all of them before the next,
+        // so that no packed FMA reads the result of the instruction just ahead of it (the round-1 order had 2/3 of
+        // them at dependency distance 2)
+        f32x2_t tt[NS], uu[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tt[s] = pk_fma(-pi[s], si[s], x);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) uu[s] = pi[s] * sr[s];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sr[s] = pk_fma(pr[s], sr[s], tt[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) si[s] = pk_fma(pr[s], si[s], uu[s]);
+#endif
         m2[0] = m1[0]; m1[0] = c0; m2[1] = m1[1]; m1[1] = c1;
     };
 
@@ -292,7 +330,7 @@ __global__ __launch_bounds__(256) void hyena_carry_add_kernel(float2* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ launch 3
-__global__ __launch_bounds__(256, 2) void hyena_apply_kernel(
+__global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
     const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, const float* __restrict__ residues,
     const uint16_t* __restrict__ dskip, const float* __restrict__ agg, uint32_t* __restrict__ y, int B, int64_t T, int D,
@@ -363,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void hyena_apply_kernel(
             f[g] = pk_fma(fc.w[g][2], c0[g], pk_fma(fc.w[g][1], m1[g], pk_fma(fc.w[g][0], m2[g], fc.b[g])));
         }
         const f32x2_t x = f[1] * f[2];             // x1 * v
+#if HY_VARIANT == 0
         f32x2_t acc = {0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -372,6 +411,29 @@ __global__ __launch_bounds__(256, 2) void hyena_apply_kernel(
             si[s] = ni;
             acc = pk_fma(rr[s], nr, pk_fma(-ri[s], ni, acc));
         }
+#else
+        // mode-parallel stages (see seg_state) and FOUR partial sums for y = Re sum_s R_s S_s instead of one
+        // 16-deep dependent chain
+        f32x2_t tt[NS], uu[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tt[s] = pk_fma(-pi[s], si[s], x);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) uu[s] = pi[s] * sr[s];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sr[s] = pk_fma(pr[s], sr[s], tt[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) si[s] = pk_fma(pr[s], si[s], uu[s]);
+        f32x2_t a4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = rr[k] * sr[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = pk_fma(rr[k + 4], sr[k + 4], a4[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = pk_fma(-ri[k], si[k], a4[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = pk_fma(-ri[k + 4], si[k + 4], a4[k]);
+        const f32x2_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#endif
         const f32x2_t out = pk_fma(x, dk, acc) * f[0];   // (y + x1v * D) * x2
 #pragma unroll
         for (int g = 0; g < 3; ++g) { m2[g] = m1[g]; m1[g] = c0[g]; }

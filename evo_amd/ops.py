@@ -23,7 +23,7 @@ _F32 = _c.c_float
 
 _SIGNATURES = {
     "evo_abi_version": ([], _c.c_int),
-    "evo_embed_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_embed_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _PTR, _PTR], _c.c_int),
     "evo_rmsnorm_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _PTR], _c.c_int),
     "evo_hyena_seg_state": ([_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_carry_scan": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
@@ -41,9 +41,11 @@ _SIGNATURES = {
     "evo_hyena_decode_fused_small_m": ([_PTR] * 12 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
+    "evo_unembed_logprob_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
 }
 
 _LIB = None
+ABI_VERSION = 2          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -63,6 +65,9 @@ def load_library(build_if_missing: bool = True) -> ctypes.CDLL:
         except Exception as e:  # noqa: BLE001
             if not path.exists():
                 raise EvoLibraryError(f"libevo_mi355x.so is missing and could not be built: {e}") from e
+            import warnings                                  # a stale binary is usable only if its ABI still matches
+            warnings.warn(f"{path} is older than its sources and the rebuild failed ({e}); loading the stale library "
+                          f"(its ABI version is checked below)")
     if not path.exists():
         raise EvoLibraryError(f"{path} not found; run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(str(path))
@@ -72,6 +77,10 @@ def load_library(build_if_missing: bool = True) -> ctypes.CDLL:
             raise EvoLibraryError(f"{path} does not export {name}")
         fn.argtypes = argtypes
         fn.restype = restype
+    got = lib.evo_abi_version()
+    if got != ABI_VERSION:
+        raise EvoLibraryError(f"{path} reports ABI version {got}, this binding needs {ABI_VERSION}: the library was built "
+                              f"from other sources -- rebuild it (python -m evo_amd._build)")
     _LIB = lib
     return lib
 
@@ -149,6 +158,8 @@ class HipOps:
         self.seg_len_override = int(os.environ.get("EVO_AMD_SEG_LEN", "0"))
         self.attn_gemm_mfma = os.environ.get("EVO_AMD_ATTN_GEMM", "mfma").lower() != "hipblaslt"
         self.timer: Optional[KernelTimer] = None
+        self.validate_ids = os.environ.get("EVO_AMD_VALIDATE_IDS", "1") != "0"   # one 4-byte D2H read per forward
+        self.last_hyena_io = {}
 
     def _t(self, name):
         return self.timer.span(name) if self.timer is not None else _NOSPAN
@@ -272,13 +283,25 @@ class HipOps:
 
     # ---- kernels -------------------------------------------------------------------------------------
     def embed(self, ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """Row gather.  Ids outside [0, vocab) raise IndexError (the reference's F.embedding device-asserts): the
+        kernel never indexes the table with them and raises a device flag, which is read back here -- except while a
+        hipGraph is being captured (no host read is possible there; the decode loop's ids come from `sample`)."""
         ids = ids.reshape(-1).to(torch.int64).contiguous()
         self._need(ids, torch.int64, "embed ids")
         self._need(weight, torch.bfloat16, "embed weight")
         V, D = weight.shape
         out = torch.empty(ids.numel(), D, dtype=torch.bfloat16, device=weight.device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        flag = None
+        if not capturing:
+            flag = getattr(self, "_embed_flag", None)
+            if flag is None or flag.device != weight.device:
+                flag = self._embed_flag = torch.zeros(1, dtype=torch.int32, device=weight.device)
         _check(self.lib.evo_embed_bf16(ids.data_ptr(), weight.data_ptr(), out.data_ptr(), ids.numel(), D, V,
-                                       _stream()), "evo_embed_bf16")
+                                       _ptr(flag), _stream()), "evo_embed_bf16")
+        if flag is not None and self.validate_ids and int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError(f"input_ids contain values outside [0, {V}) (embedding table has {V} rows)")
         return out
 
     def rmsnorm(self, x: torch.Tensor, bias: Optional[torch.Tensor], scale: torch.Tensor, eps: float) -> torch.Tensor:
@@ -332,6 +355,9 @@ class HipOps:
                                             poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
                                             y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
         state = torch.view_as_complex(s_final) if want_state else None
+        # bytes of the tensors each launch touched (bench.py prints them beside the algorithmic figure)
+        self.last_hyena_io = {"seg_state": z.numel() * 2 * 2 // 3 + agg.numel() * 4,
+                              "apply": z.numel() * 2 + y.numel() * 2 + agg.numel() * 4}
         return y, state
 
     # The same operator in two stages, for sequence parallelism: stage 1 (launches 1+2) yields the shard's end
@@ -526,9 +552,36 @@ class HipOps:
         en = torch.empty(M, dtype=torch.float32, device=logits.device) if want_entropy else None
         if target is not None:
             target = target.reshape(-1).to(torch.int64).contiguous()
+            if self.validate_ids and not torch.cuda.is_current_stream_capturing() and target.numel() \
+                    and int(target.max().item()) >= V:
+                raise IndexError(f"logprob target ids must be < {V} (negative = masked position)")
         _check(self.lib.evo_logprob_entropy(logits.data_ptr(), int(logits.dtype == torch.float32), _ptr(target),
                                             _ptr(lp), _ptr(en), M, V, _stream()),
                "evo_logprob_entropy")
+        return lp, en
+
+
+    def unembed_logprob_ok(self, h: torch.Tensor, emb: torch.Tensor) -> bool:
+        return (h.is_cuda and h.dtype == torch.bfloat16 and emb.dtype == torch.bfloat16 and h.is_contiguous()
+                and emb.is_contiguous() and emb.shape[0] == 512 and h.shape[1] % 32 == 0
+                and os.environ.get("EVO_AMD_FUSED_TAIL", "1") != "0")
+
+    def unembed_logprob(self, h: torch.Tensor, emb: torch.Tensor, target: Optional[torch.Tensor],
+                        want_logprob=True, want_entropy=False):
+        """Fused scoring tail: h [M,K] bf16 (final-norm output) x emb[512,K]^T -> (logprob [M] f32 | None,
+        entropy [M] f32 | None) without materialising the [M, 512] logits."""
+        self._need(h, torch.bfloat16, "unembed_logprob h")
+        self._need(emb, torch.bfloat16, "unembed_logprob emb")
+        M, K = h.shape
+        V = emb.shape[0]
+        lp = torch.empty(M, dtype=torch.float32, device=h.device) if want_logprob else None
+        en = torch.empty(M, dtype=torch.float32, device=h.device) if want_entropy else None
+        if target is not None:
+            target = target.reshape(-1).to(torch.int64).contiguous()
+            assert target.numel() == M
+        with self._t("unembed_logprob"):
+            _check(self.lib.evo_unembed_logprob_bf16(h.data_ptr(), emb.data_ptr(), _ptr(target), _ptr(lp), _ptr(en),
+                                                     M, V, K, _stream()), "evo_unembed_logprob_bf16")
         return lp, en
 
 

@@ -62,6 +62,41 @@ def logits_to_logprobs(logits: torch.Tensor, input_ids: torch.Tensor, trim_bos: 
     return out.to(torch.bfloat16) if bf16_logprobs else out
 
 
+def _fused_tail_ok(model, input_ids) -> bool:
+    """The fused unembed + log-softmax + gather kernel serves the engine's own model class on the GPU."""
+    ops = getattr(model, "ops", None) if hasattr(model, "hidden_states") else None
+    return (ops is not None and getattr(ops, "name", "") == "hip-gfx950" and hasattr(ops, "unembed_logprob")
+            and ops.unembed_logprob_ok(model.unembed.weight.new_empty(1, model.hidden_size), model.unembed.weight))
+
+
+def score_logprobs_device(model, input_ids: torch.Tensor, want_entropy: bool = False):
+    """What `score_sequences` / `positional_entropies` compute on the device for a BOS-prefixed id matrix [B, T]:
+    (log-prob of token t+1 at position t  [B, T-1] f32 | None, entropy of the next-token distribution [B, T-1] f32 |
+    None).  On the MI355X engine the unembedding, the log-softmax and the gather run as ONE kernel
+    (evo_unembed_logprob_bf16) and the [B, T, 512] logits are never materialised; any other model object takes
+    model(ids) -> logits_to_logprobs like the reference [REF evo/scoring.py:80-84,116-121]."""
+    B, T = input_ids.shape
+    if _fused_tail_ok(model, input_ids):
+        with torch.no_grad():
+            hid = model.hidden_states(input_ids)                       # [B*T, D] final-norm output
+            tgt = torch.full((B, T), -1, dtype=torch.int64, device=hid.device)
+            tgt[:, :-1] = input_ids[:, 1:].to(hid.device)
+            lp, en = model.ops.unembed_logprob(hid, model.unembed.weight, tgt.reshape(-1),
+                                               want_logprob=not want_entropy, want_entropy=want_entropy)
+        return (None if lp is None else lp.view(B, T)[:, :-1]), (None if en is None else en.view(B, T)[:, :-1])
+    logits, _ = model(input_ids)
+    if not want_entropy:
+        return logits_to_logprobs(logits, input_ids, trim_bos=True), None
+    logits = logits[:, :-1]                                            # BOS was prepended: drop the last prediction
+    L, V = logits.shape[1], logits.shape[2]
+    if logits.is_cuda:
+        lg = logits.reshape(B * L, V).contiguous()
+        _, ent = _ops_for(lg).logprob_entropy(lg, None, want_logprob=False, want_entropy=True)
+        return None, ent.view(B, L)
+    lsm = torch.log_softmax(logits.float(), dim=-1)
+    return None, -(lsm.exp() * lsm).sum(-1)
+
+
 def _reduce(logprobs: np.ndarray, seq_lengths: List[int], reduce_method: str) -> List[float]:
     if reduce_method == "mean":
         fn = np.mean
@@ -80,8 +115,7 @@ def score_sequences(seqs: List[str], model, tokenizer: CharLevelTokenizer, reduc
     input_ids, seq_lengths = prepare_batch(seqs, tokenizer, device=device, prepend_bos=True)
     assert len(seq_lengths) == input_ids.shape[0]
     with torch.inference_mode():
-        logits, _ = model(input_ids)                      # (batch, length, vocab)
-        logprobs = logits_to_logprobs(logits, input_ids, trim_bos=True)
+        logprobs, _ = score_logprobs_device(model, input_ids)          # (batch, length - 1)
     return _reduce(logprobs.float().cpu().numpy(), seq_lengths, reduce_method)
 
 
@@ -91,16 +125,7 @@ def positional_entropies(seqs: List[str], model, tokenizer: CharLevelTokenizer,
     input_ids, seq_lengths = prepare_batch(seqs, tokenizer, device=device, prepend_bos=True)
     assert len(seq_lengths) == input_ids.shape[0]
     with torch.inference_mode():
-        logits, _ = model(input_ids)
-        logits = logits[:, :-1]                           # BOS was prepended: drop the last prediction
-        B, L, V = logits.shape
-        if logits.is_cuda:
-            lg = logits.reshape(B * L, V).contiguous()
-            _, ent = _ops_for(lg).logprob_entropy(lg, None, want_logprob=False, want_entropy=True)
-            ent = ent.view(B, L)
-        else:
-            lsm = torch.log_softmax(logits.float(), dim=-1)
-            ent = -(lsm.exp() * lsm).sum(-1)
+        _, ent = score_logprobs_device(model, input_ids, want_entropy=True)
     ent = ent.float().cpu().numpy()
     out = [ent[i][: seq_lengths[i]] for i in range(len(seq_lengths))]
     assert all(len(s) == len(e) for s, e in zip(seqs, out))

@@ -378,12 +378,17 @@ class StripedHyena(nn.Module):
         dyn = T == 1 and mha_c is not None and getattr(mha_c, "pos_tensor", None) is not None
         if dyn:                                   # one rotary table per decode step, shared by the attention layers
             mha_c._rot_dyn = self._rotary_dyn(mha_c.pos_tensor)
+        taps = getattr(self, "block_taps", None)     # debugging / parity hook: residual stream entering every block
         try:
             for i, blk in enumerate(self.blocks):
+                if taps is not None:
+                    taps.append(h.clone())
                 if isinstance(blk, _AttentionBlock):
                     self._attn_block(i, blk, h, B, T, mha_c)
                 else:
                     self._hyena_block(i, blk, h, B, T, hy_c)
+            if taps is not None:
+                taps.append(h.clone())
         finally:
             if dyn:
                 mha_c._rot_dyn = None
@@ -424,31 +429,37 @@ class StripedHyena(nn.Module):
             all(i in mha.key_value_memory_dict for i in self.attn_layer_idxs)
 
     def _graph_decode_step(self, x, ipd):
-        mha = ipd["mha"]
+        mha, hy = ipd["mha"], ipd["hyena"]
         B = x.shape[0]
         off = int(mha.seqlen_offset)
         st = getattr(self, "_dgraph", None)
-        key = (B, id(mha), id(ipd["hyena"]), str(self.device))
         cap = min(mha.key_value_memory_dict[i].shape[1] for i in self.attn_layer_idxs) if self.attn_layer_idxs else 1 << 62
-        same_bufs = st is not None and st["key"] == key and all(
-            mha.key_value_memory_dict[i].data_ptr() == p for i, p in st["kv_ptrs"].items()) and all(
-            ipd["hyena"].state_dict[i].data_ptr() == p for i, p in st["st_ptrs"].items())
+        # The captured graph is bound to the ADDRESSES of the KV, modal-state and FIR-state tensors.  `st` keeps strong
+        # references to the cache objects and to every captured tensor and compares by identity: a later cache can then
+        # neither recycle a CPython id() nor a caching-allocator address of a freed buffer.
+        same_bufs = (st is not None and st["B"] == B and st["mha"] is mha and st["hyena"] is hy
+                     and all(mha.key_value_memory_dict.get(i) is t for i, t in st["kv"].items())
+                     and all(hy.state_dict.get(i) is t for i, t in st["iir"].items())
+                     and all(hy.fir_state_dict.get(i) is t for i, t in st["fir"].items()))
         if off + 1 > cap or not same_bufs:
             st = None
+            self._dgraph = None                      # drops the references the stale graph held
             if off + 1 > cap or any(mha.key_value_memory_dict[i].shape[0] < B for i in self.attn_layer_idxs):
                 for i in self.attn_layer_idxs:      # grow outside the graph, with headroom for the tokens to come
                     self._kv_buffer(mha, i, B, off + 1 + 4096, mha.key_value_memory_dict[i])
         try:
             if st is None:
-                if getattr(self, "_dgraph_warm", None) != key:
-                    self._dgraph_warm = key         # first step with these buffers runs eagerly (warms M=B GEMMs)
-                    self._dgraph = None
+                warm = getattr(self, "_dgraph_warm", None)
+                if warm is None or warm[0] is not mha or warm[1] is not hy or warm[2] != B:
+                    self._dgraph_warm = (mha, hy, B)  # first step with these caches runs eagerly (warms M=B GEMMs)
                     return None
                 dev = self.device
-                st = {"key": key, "ids": torch.zeros(B, 1, dtype=torch.int64, device=dev),
+                st = {"B": B, "mha": mha, "hyena": hy,
+                      "ids": torch.zeros(B, 1, dtype=torch.int64, device=dev),
                       "pos": torch.zeros(B, dtype=torch.int64, device=dev),
-                      "kv_ptrs": {i: mha.key_value_memory_dict[i].data_ptr() for i in self.attn_layer_idxs},
-                      "st_ptrs": {i: ipd["hyena"].state_dict[i].data_ptr() for i in self.hyena_layer_idxs}}
+                      "kv": {i: mha.key_value_memory_dict[i] for i in self.attn_layer_idxs},
+                      "iir": {i: hy.state_dict[i] for i in self.hyena_layer_idxs},
+                      "fir": {i: hy.fir_state_dict[i] for i in self.hyena_layer_idxs}}
                 st["ids"].copy_(x)
                 st["pos"].fill_(off)
                 mha.pos_tensor = st["pos"]
@@ -461,6 +472,10 @@ class StripedHyena(nn.Module):
                         st["pos"].add_(1)
                 finally:
                     mha.pos_tensor = None
+                # the eager decode path updates every state in place; a capture that re-bound one would replay into a
+                # buffer the cache no longer holds
+                assert all(hy.state_dict[i] is t for i, t in st["iir"].items())
+                assert all(hy.fir_state_dict[i] is t for i, t in st["fir"].items())
                 st["graph"] = g
                 st["next"] = off
                 self._dgraph = st

@@ -24,15 +24,18 @@
 extern "C" {
 #endif
 
-/* ABI version; bumped when a signature changes. */
+/* ABI version; bumped when a signature changes (the binding refuses a library whose version differs).
+ *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_* gained `mask`; evo_linear_mfma_bf16 gained `epilogue`. */
+#define EVO_ABI_VERSION 2
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
  * replaces VocabParallelEmbedding.embed (ATen gather)    [REF evo/scoring.py:81; evo/models.py:136]
- * ids [n_tok] int64, weight [vocab, D] bf16 -> out [n_tok, D] bf16.  ids outside [0,vocab) -> -1 is
- * NOT checked on device; the host validates. */
+ * ids [n_tok] int64, weight [vocab, D] bf16 -> out [n_tok, D] bf16.  An id outside [0, vocab) never
+ * indexes the table: its output row is zeros and *bad_flag (device int, may be NULL; the caller zeroes
+ * it) is set to 1 -- the binding raises IndexError where F.embedding would device-assert. */
 int evo_embed_bf16(const int64_t* ids, const void* weight, void* out,
-                   int64_t n_tok, int64_t D, int64_t vocab, void* stream);
+                   int64_t n_tok, int64_t D, int64_t vocab, int* bad_flag, void* stream);
 
 /* ---- RMSNorm -----------------------------------------------------------------------------------
  * replaces the eager RMSNorm chain (norm, div, mul)      [REF evo/configs/evo-1-8k-base_inference.yml:13,31]
@@ -184,6 +187,16 @@ int evo_gelu_gate_bf16(const void* g, void* a, int64_t M, int64_t I, void* strea
  * -> logprob [M] f32 (may be NULL), entropy [M] f32 (may be NULL).  fp32 log-softmax. */
 int evo_logprob_entropy(const void* logits, int64_t logits_f32, const int64_t* target, float* logprob,
                         float* entropy, int64_t M, int64_t V, void* stream);
+
+/* ---- fused scoring tail: unembed + log_softmax + gather (+ entropy) ---------------------------------
+ * replaces  logits = x @ E^T ; log_softmax(logits) ; gather(next token) ; -sum p log p
+ *                                                         [REF evo/scoring.py:47-57,81-84,119-121]
+ * hidden [M, K] bf16 (final-norm output), emb [V = 512, K] bf16 (tied embedding), target [M] int64 or
+ * NULL (negative = masked -> log-prob 0), logprob / entropy [M] f32 or NULL.  The [M, V] logits are
+ * never written to HBM; every logit is rounded to bf16 once (the reference's logits tensor is bf16)
+ * and the softmax statistics are taken in fp32 on the rounded values.  V must be 512, K % 32 == 0. */
+int evo_unembed_logprob_bf16(const void* hidden, const void* emb, const int64_t* target,
+                             float* logprob, float* entropy, int64_t M, int64_t V, int64_t K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.evo_abi_version.restype = ctypes.c_int
-    assert lib.evo_abi_version() == 1
+    assert lib.evo_abi_version() == evo_ops.ABI_VERSION == int(re.search(r"#define EVO_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "evo_mi355x.h")).read()).group(1))
     assert evo_ops.load_library() is not None
 
 

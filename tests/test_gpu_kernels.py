@@ -109,6 +109,28 @@ def test_logprob_entropy(ops, dtype):
     assert lp[3].item() == 0.0
 
 
+@pytest.mark.parametrize("M,K", [(1, 256), (63, 4096), (64, 4096), (513, 4096), (8193, 4096)])
+def test_fused_unembed_logprob_matches_two_kernel_path_and_oracle(ops, M, K):
+    """evo_unembed_logprob_bf16 (unembed + log-softmax + gather + entropy in one kernel, logits never in HBM) vs
+    (a) the fp64 oracle on bf16-rounded logits and (b) the two-kernel path it replaces [REF evo/scoring.py:47-57]."""
+    hid = bf(torch.randn(M, K, generator=gen(30)))
+    emb = bf(torch.randn(512, K, generator=gen(31)) * (4.0 / math.sqrt(K)))
+    tgt = torch.randint(0, 512, (M,), generator=gen(32))
+    tgt[M // 2] = -1                                                   # masked position -> log-prob 0
+    lp, en = ops.unembed_logprob(hid.to(DEV), emb.to(DEV), tgt.to(DEV), want_logprob=True, want_entropy=True)
+    logits = bf(hid.double() @ emb.double().t())                       # one rounding of every logit to bf16
+    rlp, ren = R.op_logprob_entropy(logits, tgt)
+    # a logit that lands on a rounding boundary may differ by one bf16 ulp between two fp32 summation orders
+    ulp = float(logits.abs().max()) * 2 ** -7
+    assert lp[M // 2].item() == 0.0
+    assert (lp.double().cpu() - rlp).abs().max() <= 2.5 * ulp
+    assert (en.double().cpu() - ren).abs().max() <= 2.5 * ulp
+    assert (lp.double().cpu() - rlp).abs().mean() <= 0.25 * ulp        # ... and almost none of them do
+    lg2 = ops.linear(hid.to(DEV), emb.to(DEV), None)
+    lp2, en2 = ops.logprob_entropy(lg2, tgt.to(DEV), want_logprob=True, want_entropy=True)
+    assert (lp - lp2).abs().max().item() <= 2.5 * ulp and (en - en2).abs().max().item() <= 2.5 * ulp
+
+
 # ------------------------------------------------------------------------------------------------ Hyena operator
 def hyena_params(D, seed):
     g = gen(seed)

@@ -47,7 +47,7 @@ SMALL4 = dict(vocab_size=512, hidden_size=512, num_layers=4, attn_layer_idxs=[1]
 def test_native_library_is_what_runs():
     import evo_amd.ops as eo
     ops = eo.default_ops()
-    assert ops.name == "hip-gfx950" and ops.lib.evo_abi_version() == 1
+    assert ops.name == "hip-gfx950" and ops.lib.evo_abi_version() == eo.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libevo_mi355x.so" in maps
 
@@ -121,6 +121,40 @@ def test_evo_api_scores_vs_oracle():
         assert abs(g - want) / abs(want) < 3e-3, (g, want)
         want_e = -(lsm.exp() * lsm).sum(-1).numpy()
         assert len(e) == len(s) and np.abs(e - want_e).max() < 5e-2
+
+
+def test_scoring_fused_tail_equals_logits_path(monkeypatch):
+    """score_sequences / positional_entropies through the fused unembed+log-softmax kernel == the same calls through
+    model(ids) -> logits -> evo_logprob_entropy (EVO_AMD_FUSED_TAIL=0), up to one bf16 logit ulp."""
+    import evo_amd
+    from evo_amd.tokenizer import CharLevelTokenizer
+    cfg, sd, m = build(SMALL4)
+    tok = CharLevelTokenizer(512)
+    rng = np.random.default_rng(9)
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in (257, 100, 31)]
+    a = evo_amd.score_sequences(seqs, m, tok, device=DEV)
+    ea = evo_amd.positional_entropies(seqs, m, tok, device=DEV)
+    monkeypatch.setenv("EVO_AMD_FUSED_TAIL", "0")
+    b = evo_amd.score_sequences(seqs, m, tok, device=DEV)
+    eb = evo_amd.positional_entropies(seqs, m, tok, device=DEV)
+    np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3)
+    for x, y in zip(ea, eb):
+        assert np.abs(x - y).max() < 5e-2
+
+
+def test_out_of_range_ids_raise_like_the_reference():
+    """ids outside [0, vocab) must not index the embedding table out of bounds; the reference's F.embedding
+    device-asserts, this engine raises IndexError."""
+    cfg, sd, m = build(SMALL)
+    ids = acgt(1, 40)
+    ids[0, 7] = 512
+    with pytest.raises(IndexError):
+        m(ids.to(DEV))
+    ids[0, 7] = -3
+    with pytest.raises(IndexError):
+        m(ids.to(DEV))
+    ids[0, 7] = 65
+    assert torch.isfinite(m(ids.to(DEV))[0].float()).all()           # and the flag does not stick
 
 
 def test_generate_greedy_on_gpu():
