@@ -369,7 +369,7 @@ typedef __attribute__((address_space(1))) const void* glb_void_ptr_t;
 // fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max per operand; the raw instruction is what is wanted
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // volatile: stays behind the nop fence
     return r;
 }
 
@@ -547,6 +547,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
         // row max of the (masked) tile.  (Folding these 16 v_max3 under the P.V MFMAs of the previous tile made the
         // result irreproducible from run to run -- the hand-written v_max3 then sits next to MFMAs whose hazards the
         // compiler does not model for inline asm; here it costs ~1 % and is exact.)
+        // XDL-write -> VALU-read hazard: the v_max3 below are inline asm, for which hipcc pads nothing, and on the first
+        // trip (non-diagonal first tile) only SALU / waitcnt / barrier instructions separate them from the prologue's
+        // QK^T MFMAs.  24 wait states cover the 32x32x16 result latency for every register of the tile; the fences keep
+        // the compiler from moving an MFMA below them.  (Steady state: the producers are a whole P.V phase back.)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         float tmax = row_max(s_cur);
         // running max and the (rare, exact) O rescale -- outside the pipelined blocks, which therefore have no branch
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));

@@ -24,15 +24,29 @@
 #define NS 8            // state_size   [REF evo/configs/evo-1-8k-base_inference.yml:14]
 #define HD 128          // channels per head (hidden_size / num_attention_heads)  [REF yml:2,9]
 #define CH 4            // rows (time steps) per DMA chunk
-#ifndef HY_NSLOT
-#define HY_NSLOT 6
+// Ring depth in chunks (NSLOT-1 chunks are in flight while one is consumed) and the waves per SIMD the register
+// allocation is bounded for, per kernel.  seg_state (164 VGPRs) runs 3 waves per SIMD with a 4-slot ring: -29 % time
+// against 2 waves / 6 slots at the same bytes in flight per CU (profiles/r02_hyena_notes.txt); apply needs 236 VGPRs
+// and spills at 3.
+#ifndef HY_NSLOT_S
+#define HY_NSLOT_S 4
 #endif
-#define NSLOT HY_NSLOT  // ring depth in chunks: NSLOT-1 chunks are in flight while one is consumed
+#ifndef HY_OCC_S
+#define HY_OCC_S 3
+#endif
+#ifndef HY_NSLOT_A
+#define HY_NSLOT_A 5
+#endif
+#ifndef HY_OCC_A
+#define HY_OCC_A 2
+#endif
+#ifndef HY_UNROLL_A
+#define HY_UNROLL_A 4   // steps of a chunk scheduled together in apply
+#endif
+#define HY_PRAGMA_(x) _Pragma(#x)
+#define HY_PRAGMA_UNROLL(n) HY_PRAGMA_(unroll n)
 #ifndef HY_VARIANT
-#define HY_VARIANT 1    // 0: round-1 instruction order (dependent pairs back to back); 1: mode-parallel phases
-#endif
-#ifndef HY_OCC
-#define HY_OCC 2        // waves per SIMD the register allocation is bounded for
+#define HY_VARIANT 1    // 0: round-1 instruction order (dependent pairs back to back); 1: mode-parallel stages
 #endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -106,32 +120,22 @@ struct ChunkMap {
 // outstanding as were issued after chunk c's DMA".  In the steady state that is, per ring stage, NDMA DMA
 // instructions plus the y stores of one chunk (apply: 4; seg_state: 0), times NSLOT-1 stages.  Counting the
 // stores matters: waiting them out too (vmcnt(15)) stalled every chunk on the ~2 us store latency.
-#define HY_STR2(x) #x
-#define HY_STR(x) HY_STR2(x)
-#define HY_WAIT_STATE() asm volatile("s_waitcnt vmcnt(" HY_STR(HY_VM_STATE) ")" ::: "memory")   /* 2 DMA x (NSLOT-1) stages            */
-#define HY_WAIT_APPLY() asm volatile("s_waitcnt vmcnt(" HY_STR(HY_VM_APPLY) ")" ::: "memory")   /* (3 DMA + 4 stores) x (NSLOT-1) stages */
-#if HY_NSLOT == 6
-#define HY_VM_STATE 10
-#define HY_VM_APPLY 35
-#elif HY_NSLOT == 5
-#define HY_VM_STATE 8
-#define HY_VM_APPLY 28
-#elif HY_NSLOT == 4
-#define HY_VM_STATE 6
-#define HY_VM_APPLY 21
-#else
-#error "HY_NSLOT must be 4, 5 or 6 (the vmcnt immediates are tabulated)"
-#endif
+#define HY_WAIT_STATE() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (HY_NSLOT_S - 1)) : "memory")   /* 2 DMA x stages in flight            */
+#define HY_WAIT_APPLY() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * (HY_NSLOT_A - 1)) : "memory")   /* (3 DMA + 4 stores) x stages in flight */
 static_assert(CH == 4, "HY_WAIT_* immediates assume 4 stores per chunk");
+static_assert(7 * (HY_NSLOT_A - 1) <= 63 && HY_NSLOT_S >= 2 && HY_NSLOT_A >= 2, "vmcnt is a 6-bit field");
 
 // ------------------------------------------------------------------------------------------------ launch 1
-__global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
+// MASK: upstream's padding_mask [B, T] (1 = token, 0 = pad) multiplies the FIR output, i.e. x2, x1 and v of a padded
+// position are zero: it injects nothing into the modes and its y is zero.  evo never passes one.
+template <bool MASK>
+__global__ __launch_bounds__(256, HY_OCC_S) void hyena_seg_state_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
-    const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, float* __restrict__ agg, int B, int64_t T,
-    int D, int H, int C, int n_seg) {
+    const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, float* __restrict__ agg,
+    const uint8_t* __restrict__ mask, int B, int64_t T, int D, int H, int C, int n_seg) {
     constexpr int ROWB = 2 * HD * 2;                                   // x1|v = 512 B
     typedef ChunkMap<ROWB> Map;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NSLOT * Map::CHUNKB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HY_NSLOT_S * Map::CHUNKB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;                 // wave-uniform (SGPR)
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
     const int64_t rowbytes = rowdw * 4;
     const int64_t t0 = (int64_t)seg * C;
     const int64_t t1 = (t0 + C < T) ? t0 + C : T;
-    unsigned char* ring = smem + wave * (NSLOT * Map::CHUNKB);
+    unsigned char* ring = smem + wave * (HY_NSLOT_S * Map::CHUNKB);
 
     const uint32_t* zb = z + (int64_t)b * T * rowdw;
     const unsigned char* zbb = (const unsigned char*)zb;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
     map.init(lane, (h * 3 * HD + HD) * 2);
     const int nch = (int)((t1 - t0 + CH - 1) / CH);
 #pragma unroll
-    for (int c = 0; c < NSLOT - 1; ++c)
+    for (int c = 0; c < HY_NSLOT_S - 1; ++c)
         if (c < nch) map.issue(zbb, t0 + CH * c, T - 1, rowbytes, ring + c * Map::CHUNKB);
 
     FirCoef fc;
@@ -176,11 +180,13 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
     m1[0] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col1));
     m1[1] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col2));
 
-    auto step = [&](uint32_t zx1, uint32_t zv) {
+    const uint8_t* mrow = MASK ? mask + (int64_t)b * T : nullptr;
+    auto step = [&](uint32_t zx1, uint32_t zv, int64_t t_abs) {
         const f32x2_t c0 = bf2_unpack(zx1), c1 = bf2_unpack(zv);
         const f32x2_t x1c = pk_fma(fc.w[1][2], c0, pk_fma(fc.w[1][1], m1[0], pk_fma(fc.w[1][0], m2[0], fc.b[1])));
         const f32x2_t vc = pk_fma(fc.w[2][2], c1, pk_fma(fc.w[2][1], m1[1], pk_fma(fc.w[2][0], m2[1], fc.b[2])));
-        const f32x2_t x = x1c * vc;
+        f32x2_t x = x1c * vc;
+        if (MASK) x = x * (mrow[t_abs] ? 1.f : 0.f);
 #if HY_VARIANT == 0
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -209,10 +215,10 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
     // prologue chunks + parameter loads have all landed past this point: the counted waits below only ever
     // reason about VMEM ops issued inside the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int slot = 0, fill = NSLOT - 1;
+    int slot = 0, fill = HY_NSLOT_S - 1;
     for (int c = 0; c < nch; ++c) {
-        if (c + NSLOT - 1 < nch) {
-            map.issue(zbb, t0 + CH * (int64_t)(c + NSLOT - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
+        if (c + HY_NSLOT_S - 1 < nch) {
+            map.issue(zbb, t0 + CH * (int64_t)(c + HY_NSLOT_S - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
             HY_WAIT_STATE();                               // chunk c has landed; 5 younger chunks stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,13 +228,13 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_seg_state_kernel(
         if (tb + CH <= t1) {                               // full chunk: one basic block, 4 steps scheduled together
 #pragma unroll
             for (int k = 0; k < CH; ++k)
-                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256));
+                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256), tb + k);
         } else {                                           // ragged end of the sequence
             for (int k = 0; k < CH && tb + k < t1; ++k)
-                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256));
+                step(*(const uint32_t*)(sp + k * ROWB), *(const uint32_t*)(sp + k * ROWB + 256), tb + k);
         }
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-        fill = fill + 1 == NSLOT ? 0 : fill + 1;
+        slot = slot + 1 == HY_NSLOT_S ? 0 : slot + 1;
+        fill = fill + 1 == HY_NSLOT_S ? 0 : fill + 1;
     }
 
     float4* out = (float4*)(agg + ((((int64_t)b * n_seg + seg) * D + h * HD + 2 * lane) * NS) * 2);
@@ -330,14 +336,15 @@ __global__ __launch_bounds__(256) void hyena_carry_add_kernel(float2* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ launch 3
-__global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
+template <bool MASK>
+__global__ __launch_bounds__(256, HY_OCC_A) void hyena_apply_kernel(
     const uint32_t* __restrict__ z, const uint32_t* __restrict__ z_halo, const uint16_t* __restrict__ fir_w,
     const uint16_t* __restrict__ fir_b, const float* __restrict__ poles, const float* __restrict__ residues,
-    const uint16_t* __restrict__ dskip, const float* __restrict__ agg, uint32_t* __restrict__ y, int B, int64_t T, int D,
-    int H, int C, int n_seg) {
+    const uint16_t* __restrict__ dskip, const float* __restrict__ agg, uint32_t* __restrict__ y,
+    const uint8_t* __restrict__ mask, int B, int64_t T, int D, int H, int C, int n_seg) {
     constexpr int ROWB = 3 * HD * 2;                                   // x2|x1|v = 768 B
     typedef ChunkMap<ROWB> Map;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NSLOT * Map::CHUNKB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HY_NSLOT_A * Map::CHUNKB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;                 // wave-uniform (SGPR)
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
     const int64_t rowbytes = rowdw * 4;
     const int64_t t0 = (int64_t)seg * C;
     const int64_t t1 = (t0 + C < T) ? t0 + C : T;
-    unsigned char* ring = smem + wave * (NSLOT * Map::CHUNKB);
+    unsigned char* ring = smem + wave * (HY_NSLOT_A * Map::CHUNKB);
 
     const uint32_t* zb = z + (int64_t)b * T * rowdw;
     const unsigned char* zbb = (const unsigned char*)zb;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
     map.init(lane, (h * 3 * HD) * 2);
     const int nch = (int)((t1 - t0 + CH - 1) / CH);
 #pragma unroll
-    for (int c = 0; c < NSLOT - 1; ++c)
+    for (int c = 0; c < HY_NSLOT_A - 1; ++c)
         if (c < nch) map.issue(zbb, t0 + CH * c, T - 1, rowbytes, ring + c * Map::CHUNKB);
 
     FirCoef fc;
@@ -393,12 +400,18 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
         m1[g] = bf2_unpack(load_hist(zb, hb, t0 - 1, rowdw, col0 + g * (HD / 2)));
     }
 
-    auto step = [&](const uint32_t (&zr)[3]) -> uint32_t {
+    const uint8_t* mrow = MASK ? mask + (int64_t)b * T : nullptr;
+    auto step = [&](const uint32_t (&zr)[3], int64_t t_abs) -> uint32_t {
         f32x2_t c0[3], f[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             c0[g] = bf2_unpack(zr[g]);
             f[g] = pk_fma(fc.w[g][2], c0[g], pk_fma(fc.w[g][1], m1[g], pk_fma(fc.w[g][0], m2[g], fc.b[g])));
+        }
+        if (MASK) {                                // padded position: x2 = x1 = v = 0
+            const float mk = mrow[t_abs] ? 1.f : 0.f;
+            f[0] = f[0] * mk;
+            f[1] = f[1] * mk;
         }
         const f32x2_t x = f[1] * f[2];             // x1 * v
 #if HY_VARIANT == 0
@@ -445,10 +458,10 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
     // prologue chunks + parameter loads have all landed past this point: the counted waits below only ever
     // reason about VMEM ops issued inside the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int slot = 0, fill = NSLOT - 1;
+    int slot = 0, fill = HY_NSLOT_A - 1;
     for (int c = 0; c < nch; ++c) {
-        if (c + NSLOT - 1 < nch) {
-            map.issue(zbb, t0 + CH * (int64_t)(c + NSLOT - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
+        if (c + HY_NSLOT_A - 1 < nch) {
+            map.issue(zbb, t0 + CH * (int64_t)(c + HY_NSLOT_A - 1), T - 1, rowbytes, ring + fill * Map::CHUNKB);
             HY_WAIT_APPLY();                               // chunk c has landed; 5 younger chunks stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,24 +469,24 @@ __global__ __launch_bounds__(256, HY_OCC) void hyena_apply_kernel(
         const unsigned char* sp = ring + slot * Map::CHUNKB + 4 * lane;
         const int64_t tb = t0 + CH * (int64_t)c;
         if (tb + CH <= t1) {                               // full chunk: one basic block, 4 steps scheduled together
-#pragma unroll
+HY_PRAGMA_UNROLL(HY_UNROLL_A)
             for (int k = 0; k < CH; ++k) {
                 uint32_t zr[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) zr[g] = *(const uint32_t*)(sp + k * ROWB + g * 256);
-                yp[(int64_t)k * ydw] = step(zr);
+                yp[(int64_t)k * ydw] = step(zr, tb + k);
             }
         } else {                                           // ragged end of the sequence
             for (int k = 0; k < CH && tb + k < t1; ++k) {
                 uint32_t zr[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) zr[g] = *(const uint32_t*)(sp + k * ROWB + g * 256);
-                yp[(int64_t)k * ydw] = step(zr);
+                yp[(int64_t)k * ydw] = step(zr, tb + k);
             }
         }
         yp += (int64_t)CH * ydw;
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-        fill = fill + 1 == NSLOT ? 0 : fill + 1;
+        slot = slot + 1 == HY_NSLOT_A ? 0 : slot + 1;
+        fill = fill + 1 == HY_NSLOT_A ? 0 : fill + 1;
     }
 }
 
@@ -538,14 +551,20 @@ static int hyena_check(int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t
 }
 
 extern "C" int evo_hyena_seg_state(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
-                                   const float* poles, float* agg, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                                   int64_t seg_len, void* stream) {
+                                   const float* poles, float* agg, const uint8_t* mask, int64_t B, int64_t T, int64_t D,
+                                   int64_t n_heads, int64_t seg_len, void* stream) {
     if (hyena_check(B, T, D, n_heads, seg_len)) return -1;
     const int n_seg = (int)((T + seg_len - 1) / seg_len);
     const int64_t waves = B * n_seg * n_heads;
-    hipLaunchKernelGGL(hyena_seg_state_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint32_t*)z, (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles,
-                       agg, (int)B, T, (int)D, (int)n_heads, (int)seg_len, n_seg);
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (mask)
+        hipLaunchKernelGGL(hyena_seg_state_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint32_t*)z,
+                           (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, agg, mask, (int)B,
+                           T, (int)D, (int)n_heads, (int)seg_len, n_seg);
+    else
+        hipLaunchKernelGGL(hyena_seg_state_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint32_t*)z,
+                           (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, agg, mask, (int)B,
+                           T, (int)D, (int)n_heads, (int)seg_len, n_seg);
     return evo_launch_status();
 }
 
@@ -572,14 +591,22 @@ extern "C" int evo_hyena_carry_add(float* agg, const float* poles, const float* 
 
 extern "C" int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
                                const float* poles, const float* residues, const void* dskip, const float* agg, void* y,
-                               int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream) {
+                               const uint8_t* mask, int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len,
+                               void* stream) {
     if (hyena_check(B, T, D, n_heads, seg_len)) return -1;
     const int n_seg = (int)((T + seg_len - 1) / seg_len);
     const int64_t waves = B * n_seg * n_heads;
-    hipLaunchKernelGGL(hyena_apply_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint32_t*)z, (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles,
-                       residues, (const uint16_t*)dskip, agg, (uint32_t*)y, (int)B, T, (int)D, (int)n_heads, (int)seg_len,
-                       n_seg);
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (mask)
+        hipLaunchKernelGGL(hyena_apply_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint32_t*)z,
+                           (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, residues,
+                           (const uint16_t*)dskip, agg, (uint32_t*)y, mask, (int)B, T, (int)D, (int)n_heads, (int)seg_len,
+                           n_seg);
+    else
+        hipLaunchKernelGGL(hyena_apply_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint32_t*)z,
+                           (const uint32_t*)z_halo, (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, residues,
+                           (const uint16_t*)dskip, agg, (uint32_t*)y, mask, (int)B, T, (int)D, (int)n_heads, (int)seg_len,
+                           n_seg);
     return evo_launch_status();
 }
 

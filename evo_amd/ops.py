@@ -25,10 +25,10 @@ _SIGNATURES = {
     "evo_abi_version": ([], _c.c_int),
     "evo_embed_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _PTR, _PTR], _c.c_int),
     "evo_rmsnorm_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _PTR], _c.c_int),
-    "evo_hyena_seg_state": ([_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_hyena_seg_state": ([_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_carry_scan": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_carry_add": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
-    "evo_hyena_apply": ([_PTR] * 9 + [_I64] * 5 + [_PTR], _c.c_int),
+    "evo_hyena_apply": ([_PTR] * 10 + [_I64] * 5 + [_PTR], _c.c_int),
     "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR], _c.c_int),
@@ -291,16 +291,13 @@ class HipOps:
         self._need(weight, torch.bfloat16, "embed weight")
         V, D = weight.shape
         out = torch.empty(ids.numel(), D, dtype=torch.bfloat16, device=weight.device)
-        capturing = torch.cuda.is_current_stream_capturing()
-        flag = None
-        if not capturing:
-            flag = getattr(self, "_embed_flag", None)
-            if flag is None or flag.device != weight.device:
-                flag = self._embed_flag = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        # a fresh 4-byte flag per call (a cached one would be an inference tensor when first made under
+        # torch.inference_mode and could not be reset outside it); none while a hipGraph is being captured
+        flag = None if torch.cuda.is_current_stream_capturing() or not self.validate_ids else \
+            torch.zeros(1, dtype=torch.int32, device=weight.device)
         _check(self.lib.evo_embed_bf16(ids.data_ptr(), weight.data_ptr(), out.data_ptr(), ids.numel(), D, V,
                                        _ptr(flag), _stream()), "evo_embed_bf16")
-        if flag is not None and self.validate_ids and int(flag.item()) != 0:
-            flag.zero_()
+        if flag is not None and int(flag.item()) != 0:
             raise IndexError(f"input_ids contain values outside [0, {V}) (embedding table has {V} rows)")
         return out
 
@@ -320,9 +317,13 @@ class HipOps:
     def hyena_prefill(self, z: torch.Tensor, fir_w: torch.Tensor, fir_b: torch.Tensor, poles: torch.Tensor,
                       residues: torch.Tensor, dskip: torch.Tensor, n_heads: int,
                       z_halo: Optional[torch.Tensor] = None, s0: Optional[torch.Tensor] = None,
-                      want_state: bool = False, seg_len: Optional[int] = None
-                      ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """z [B,T,3D] bf16 -> y [B,T,D] bf16 (+ complex64 state [B,D,8] after the last token)."""
+                      want_state: bool = False, seg_len: Optional[int] = None,
+                      mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """z [B,T,3D] bf16 -> y [B,T,D] bf16 (+ complex64 state [B,D,8] after the last token).  `mask` [B,T] (bool /
+        uint8, 1 = token) is upstream's padding_mask: padded positions get a zero FIR output."""
+        if mask is not None:
+            mask = mask.to(device=z.device, dtype=torch.uint8).contiguous()
+            assert mask.shape == z.shape[:2]
         self._need(z, torch.bfloat16, "hyena z")
         B, T, D3 = z.shape
         D = D3 // 3
@@ -345,7 +346,7 @@ class HipOps:
         st = _stream()
         with self._t("hyena_seg_state"):
             _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                                poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+                                                poles.data_ptr(), agg.data_ptr(), _ptr(mask), B, T, D, n_heads, C, st),
                    "evo_hyena_seg_state")
         with self._t("hyena_carry_scan"):
             _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), _ptr(s0r), _ptr(s_final), B, T, D,
@@ -353,7 +354,7 @@ class HipOps:
         with self._t("hyena_apply"):
             _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
                                             poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
-                                            y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
+                                            y.data_ptr(), _ptr(mask), B, T, D, n_heads, C, st), "evo_hyena_apply")
         state = torch.view_as_complex(s_final) if want_state else None
         # bytes of the tensors each launch touched (bench.py prints them beside the algorithmic figure)
         self.last_hyena_io = {"seg_state": z.numel() * 2 * 2 // 3 + agg.numel() * 4,
@@ -373,7 +374,7 @@ class HipOps:
         st = _stream()
         with self._t("hyena_seg_state"):
             _check(self.lib.evo_hyena_seg_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                                poles.data_ptr(), agg.data_ptr(), B, T, D, n_heads, C, st),
+                                                poles.data_ptr(), agg.data_ptr(), None, B, T, D, n_heads, C, st),
                    "evo_hyena_seg_state")
         with self._t("hyena_carry_scan"):
             _check(self.lib.evo_hyena_carry_scan(agg.data_ptr(), poles.data_ptr(), None, s_end.data_ptr(), B, T, D, C,
@@ -394,7 +395,7 @@ class HipOps:
         with self._t("hyena_apply"):
             _check(self.lib.evo_hyena_apply(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
                                             poles.data_ptr(), residues.data_ptr(), dskip.data_ptr(), agg.data_ptr(),
-                                            y.data_ptr(), B, T, D, n_heads, C, st), "evo_hyena_apply")
+                                            y.data_ptr(), None, B, T, D, n_heads, C, st), "evo_hyena_apply")
         return y
 
     def hyena_step(self, z_t: torch.Tensor, fir_state: torch.Tensor, iir_state: torch.Tensor, fir_w, fir_b, poles,

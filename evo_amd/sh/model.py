@@ -276,8 +276,17 @@ class StripedHyena(nn.Module):
         self.ops.linear_residual_(x2d, y, w, mfma=mfma)
         return bias
 
-    def _mlp_residual_(self, blk, x2d, bias):
+    def _mlp_residual_(self, blk, x2d, bias, mask=None):
         ops = self.ops
+        if mask is not None:                                             # upstream: (mixer out + u) * padding_mask
+            if bias is not None:
+                x2d.add_(bias)
+                bias = None
+            x2d.mul_(mask)
+            n2 = ops.rmsnorm(x2d, None, blk.post_norm.scale, self.eps)
+            a = ops.mlp_gate(n2, blk.mlp._w12)
+            ops.linear_residual_(x2d, a, blk.mlp._w3)
+            return
         if bias is None:                                                 # decode: norm + l1/l2 + gate in one launch
             a = ops.mlp_gate(x2d, blk.mlp._w12, blk.post_norm.scale, self.eps)
         else:
@@ -285,7 +294,10 @@ class StripedHyena(nn.Module):
             a = ops.mlp_gate(n2, blk.mlp._w12)
         ops.linear_residual_(x2d, a, blk.mlp._w3)
 
-    def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams]):
+    def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams], mask=None):
+        """`mask` = (flat [B*T,1] bf16, [B,T] uint8) of upstream's padding_mask, or None: the projections output, the FIR
+        output and the mixer output + residual are multiplied by it, as upstream's ParallelGatedConvBlock /
+        engine.parallel_fir do [UPSTREAM-RECALLED; evo never passes one, SURVEY 8b]."""
         ops = self.ops
         D, H = self.hidden_size, self.num_heads
         f = blk.filter
@@ -296,13 +308,16 @@ class StripedHyena(nn.Module):
                                        f._poles, f._residues, f.D, H)
         else:
             z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
+            if mask is not None:
+                z.mul_(mask[0])
             z3 = z.view(B, T, 3 * D)
             halo = s0 = None
             if have_state:                      # continue a cached prefix with more than one token
                 halo = cache.fir_state_dict[i].transpose(1, 2).contiguous()
                 s0 = cache.state_dict[i]
+            kw = {} if mask is None else {"mask": mask[1]}
             y3, state = ops.hyena_prefill(z3, f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H,
-                                          z_halo=halo, s0=s0, want_state=cache is not None)
+                                          z_halo=halo, s0=s0, want_state=cache is not None, **kw)
             y = y3.view(B * T, D)
             if cache is not None:
                 K1 = self.short_filter_length - 1
@@ -313,7 +328,8 @@ class StripedHyena(nn.Module):
                     tail = torch.cat([z3.new_zeros(B, K1 - T, 3 * D), tail], dim=1)
                 cache.fir_state_dict[i] = tail.transpose(1, 2).contiguous()      # [B, 3D, 2]
                 cache.state_dict[i] = state
-        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias))
+        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias),
+                            None if mask is None else mask[0])
 
     def _kv_buffer(self, cache: InferenceParams, i: int, B: int, need: int, like: torch.Tensor):
         H, hd = self.num_heads, self.head_dim
@@ -330,10 +346,12 @@ class StripedHyena(nn.Module):
             cache.key_value_memory_dict[i] = kv = new
         return kv
 
-    def _attn_block(self, i, blk, x2d, B, T, cache: Optional[InferenceParams]):
+    def _attn_block(self, i, blk, x2d, B, T, cache: Optional[InferenceParams], mask=None):
         ops = self.ops
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         mha = blk.inner_mha_cls
+        if mask is not None:                      # upstream AttentionBlock: u * padding_mask before and after the mixer
+            x2d.mul_(mask[0])
         qkv = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
         off = int(cache.seqlen_offset) if cache is not None else 0
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
@@ -361,10 +379,11 @@ class StripedHyena(nn.Module):
                 a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
             else:
                 a = ops.attention(q, k, v, off).view(B * T, D)
-        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias, mfma=True))
+        self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias, mfma=True),
+                            None if mask is None else mask[0])
 
     # ------------------------------------------------------------------ forward
-    def hidden_states(self, x: torch.Tensor, inference_params_dict=None) -> torch.Tensor:
+    def hidden_states(self, x: torch.Tensor, inference_params_dict=None, padding_mask=None) -> torch.Tensor:
         """ids [B,T] -> final-norm hidden states [B*T, D] (logits = hidden @ E^T)."""
         if not self._packed:
             self._pack()
@@ -373,6 +392,12 @@ class StripedHyena(nn.Module):
         B, T = x.shape
         ops = self.ops
         h = ops.embed(x.to(self.device), self.embedding_layer.weight)             # [B*T, D]
+        mask = None
+        if padding_mask is not None:
+            if tuple(padding_mask.shape) != (B, T):
+                raise ValueError(f"padding_mask must be [batch, length] = {(B, T)}, got {tuple(padding_mask.shape)}")
+            pm = padding_mask.to(self.device) != 0
+            mask = (pm.reshape(B * T, 1).to(h.dtype), pm.to(torch.uint8).contiguous())
         mha_c = inference_params_dict["mha"] if inference_params_dict is not None else None
         hy_c = inference_params_dict["hyena"] if inference_params_dict is not None else None
         dyn = T == 1 and mha_c is not None and getattr(mha_c, "pos_tensor", None) is not None
@@ -384,9 +409,9 @@ class StripedHyena(nn.Module):
                 if taps is not None:
                     taps.append(h.clone())
                 if isinstance(blk, _AttentionBlock):
-                    self._attn_block(i, blk, h, B, T, mha_c)
+                    self._attn_block(i, blk, h, B, T, mha_c, mask)
                 else:
-                    self._hyena_block(i, blk, h, B, T, hy_c)
+                    self._hyena_block(i, blk, h, B, T, hy_c, mask)
             if taps is not None:
                 taps.append(h.clone())
         finally:
@@ -398,11 +423,16 @@ class StripedHyena(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, inference_params_dict=None, padding_mask=None):
-        """(logits [B,T,V] bf16, cache-or-None).  `padding_mask` is accepted for signature parity; evo never
-        passes it [REF evo/scoring.py:81; evo/generation.py:152-155] and pads are ordinary tokens."""
-        if padding_mask is not None:
-            raise NotImplementedError("padding_mask is not used on the evo path and is not supported")
+        """(logits [B,T,V] bf16, cache-or-None).  `padding_mask` [B,T] (1 = token, 0 = pad) is applied as upstream
+        applies it (block inputs / FIR output / mixer output multiplied by it); evo itself never passes one
+        [REF evo/scoring.py:81; evo/generation.py:152-155] -- without it pads are ordinary tokens.  It is a prefill /
+        scoring option: a single-token decode step takes no mask."""
         B, T = x.shape
+        if padding_mask is not None:
+            if T == 1 and inference_params_dict is not None:
+                raise ValueError("padding_mask applies to the parallel (prefill / scoring) forward, not to a decode step")
+            h = self.hidden_states(x, inference_params_dict, padding_mask)
+            return self.ops.linear(h, self.unembed.weight, None).view(B, T, self.vocab_size), inference_params_dict
         if T == 1 and inference_params_dict is not None and self._graph_eligible(inference_params_dict):
             logits = self._graph_decode_step(x, inference_params_dict)
             if logits is not None:

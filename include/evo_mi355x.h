@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 /* ABI version; bumped when a signature changes (the binding refuses a library whose version differs).
- *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_* gained `mask`; evo_linear_mfma_bf16 gained `epilogue`. */
+ *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_seg_state / evo_hyena_apply gained `mask`;
+ *      evo_unembed_logprob_bf16 added. */
 #define EVO_ABI_VERSION 2
 int evo_abi_version(void);
 
@@ -69,9 +70,11 @@ int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out,
  *   s0       [B, D, 8] c64 or NULL: state entering t=0 (sequence-parallel carry-in / resumed prefill)
  *   s_final  [B, D, 8] c64 or NULL: state after t=T-1  (== upstream prefill_via_modal_fft)
  *   y        [B, T, D] bf16     (y_conv + x1v * dskip) * x2, channel-last
+ *   mask     [B, T] uint8 or NULL: upstream's `padding_mask` (1 = token, 0 = pad): the FIR output (x2, x1, v) of
+ *                               a padded position is zero, as engine.parallel_fir multiplies it.  evo never passes one.
  */
 int evo_hyena_seg_state(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
-                        const float* poles, float* agg,
+                        const float* poles, float* agg, const uint8_t* mask,
                         int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
 int evo_hyena_carry_scan(float* agg, const float* poles, const float* s0, float* s_final,
                          int64_t B, int64_t T, int64_t D, int64_t seg_len, void* stream);
@@ -81,7 +84,7 @@ int evo_hyena_carry_add(float* agg, const float* poles, const float* s0,
                         int64_t B, int64_t T, int64_t D, int64_t seg_len, void* stream);
 int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const void* fir_b,
                     const float* poles, const float* residues, const void* dskip,
-                    const float* agg, void* y,
+                    const float* agg, void* y, const uint8_t* mask,
                     int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------

@@ -266,8 +266,10 @@ class RefStripedHyena:
         y = torch.fft.irfft(X * H, n=n, norm="forward")[..., :T]
         return y
 
-    def hyena_filter_parallel(self, z_cl, pre, want_state: bool):
+    def hyena_filter_parallel(self, z_cl, pre, want_state: bool, padding_mask=None):
         zc = self.fir(z_cl, pre)
+        if padding_mask is not None:              # upstream engine.parallel_fir: z_pre * padding_mask[:, None]
+            zc = zc * padding_mask[:, None, :].to(zc.dtype)
         x2, x1, v = self.column_split(zc)
         x1v = x1 * v
         T = x1v.shape[-1]
@@ -356,16 +358,21 @@ class RefStripedHyena:
         return out
 
     # ---- blocks ----------------------------------------------------------------
-    def hyena_block(self, u, i, cache: Optional[RefRecurrentInferenceParams]):
+    def hyena_block(self, u, i, cache: Optional[RefRecurrentInferenceParams], padding_mask=None):
+        """upstream ParallelGatedConvBlock.forward; with a padding_mask [B,T] the projections output, the FIR output and
+        (mixer output + residual) are multiplied by it [UPSTREAM-RECALLED]."""
         pre = f"blocks.{i}."
         z = self.linear(self.rmsnorm(u, self.w[pre + "pre_norm.scale"]),
                         self.w[pre + "projections.weight"], self.w[pre + "projections.bias"])
+        pm = None if padding_mask is None else padding_mask[..., None].to(u.dtype)
+        if pm is not None:
+            z = z * pm
         if cache is not None and i in cache.fir_state_dict:
             y, nf, ns = self.hyena_filter_step(z[:, 0], pre, cache.fir_state_dict[i], cache.state_dict[i])
             cache.fir_state_dict[i] = nf
             cache.state_dict[i] = ns
         else:
-            y, state = self.hyena_filter_parallel(z, pre, want_state=cache is not None)
+            y, state = self.hyena_filter_parallel(z, pre, want_state=cache is not None, padding_mask=padding_mask)
             if cache is not None:
                 zt = z.transpose(1, 2)
                 K1 = self.cfg.short_filter_length - 1
@@ -375,10 +382,16 @@ class RefStripedHyena:
                 cache.fir_state_dict[i] = fs.clone()
                 cache.state_dict[i] = state
         u2 = self.linear(y, self.w[pre + "out_filter_dense.weight"], self.w[pre + "out_filter_dense.bias"]) + u
+        if pm is not None:
+            u2 = u2 * pm
         return self.mlp(self.rmsnorm(u2, self.w[pre + "post_norm.scale"]), pre) + u2
 
-    def attn_block(self, u, i, cache: Optional[RefInferenceParams]):
+    def attn_block(self, u, i, cache: Optional[RefInferenceParams], padding_mask=None):
+        """upstream AttentionBlock.forward; a padding_mask multiplies u before and after the mixer [UPSTREAM-RECALLED]."""
         pre = f"blocks.{i}."
+        pm = None if padding_mask is None else padding_mask[..., None].to(u.dtype)
+        if pm is not None:
+            u = u * pm
         B, T, D = u.shape
         H, hd = self.cfg.num_attention_heads, self.cfg.head_dim
         qkv = self.linear(self.rmsnorm(u, self.w[pre + "pre_norm.scale"]),
@@ -401,6 +414,8 @@ class RefStripedHyena:
         a = self.attention(q, k, v, q_pos0=off).reshape(B, T, D)
         u2 = self.linear(a, self.w[pre + "inner_mha_cls.out_proj.weight"],
                          self.w[pre + "inner_mha_cls.out_proj.bias"]) + u
+        if pm is not None:
+            u2 = u2 * pm
         return self.mlp(self.rmsnorm(u2, self.w[pre + "post_norm.scale"]), pre) + u2
 
     # ---- top level -----------------------------------------------------------------
@@ -412,13 +427,13 @@ class RefStripedHyena:
         }
 
     @torch.no_grad()
-    def forward(self, ids: torch.Tensor, inference_params_dict=None, return_hidden: bool = False):
+    def forward(self, ids: torch.Tensor, inference_params_dict=None, return_hidden: bool = False, padding_mask=None):
         x = self.w["embedding_layer.weight"][ids.long()]
         for i in range(self.cfg.num_layers):
             if i in self.cfg.attn_layer_idxs:
-                x = self.attn_block(x, i, inference_params_dict["mha"] if inference_params_dict else None)
+                x = self.attn_block(x, i, inference_params_dict["mha"] if inference_params_dict else None, padding_mask)
             else:
-                x = self.hyena_block(x, i, inference_params_dict["hyena"] if inference_params_dict else None)
+                x = self.hyena_block(x, i, inference_params_dict["hyena"] if inference_params_dict else None, padding_mask)
         x = self.rmsnorm(x, self.w["norm.scale"])
         if return_hidden:
             return x
@@ -487,7 +502,7 @@ def op_rmsnorm(x, scale, eps, bias=None, hi=torch.float64):
     return xh, scale.to(hi) * (xh / den)
 
 
-def op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo=None, s0=None, hi=torch.float64):
+def op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo=None, s0=None, hi=torch.float64, mask=None):
     """evo_hyena_{seg_state,carry_scan,apply}: z [B,T,3D] -> (y [B,T,D], state [B,D,S] complex) in `hi`.
     poles/residues [D,S,2]; fir_w [3D,K]; z_halo [B,K-1,3D] (rows before t=0) or None; s0 complex or None."""
     B, T, D3 = z.shape
@@ -499,6 +514,8 @@ def op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo=None, s0=N
     zp = torch.cat([left, zt], dim=-1)
     w = fir_w.to(hi)
     zc = sum(w[None, :, k, None] * zp[..., k:k + T] for k in range(K)) + fir_b.to(hi)[None, :, None]
+    if mask is not None:                                            # padding_mask on the FIR output
+        zc = zc * (mask != 0).to(hi)[:, None, :]
     hd = D // n_heads
     z4 = zc.reshape(B, n_heads, 3 * hd, T)
     x2 = z4[:, :, :hd].reshape(B, D, T)

@@ -41,8 +41,8 @@ class OracleOps:
         return self._o(n)
 
     def hyena_prefill(self, z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo=None, s0=None,
-                      want_state=False, seg_len=None):
-        y, st = R.op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo, s0)
+                      want_state=False, seg_len=None, mask=None):
+        y, st = R.op_hyena(z, fir_w, fir_b, poles, residues, dskip, n_heads, z_halo, s0, mask=mask)
         return self._o(y), (st.to(torch.complex64 if self.act != torch.float64 else torch.complex128)
                             if want_state else None)
 

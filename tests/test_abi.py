@@ -41,8 +41,13 @@ def test_argument_validation_needs_no_gpu():
     lib = evo_ops.load_library()
     # bad shapes are rejected on the host before any launch
     assert lib.evo_rmsnorm_bf16(None, None, None, None, 4, 7, 1e-6, None) == -1
-    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, 1, 16, 256, 3, 64, None) == -1
-    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, 1, 16, 256, 2, 6, None) == -1
+    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, None, 1, 16, 256, 3, 64, None) == -1
+    assert lib.evo_hyena_apply(None, None, None, None, None, None, None, None, None, None, 1, 16, 256, 2, 6, None) == -1
+    assert lib.evo_hyena_seg_state(None, None, None, None, None, None, None, 1, 16, 256, 2, 6, None) == -1
+    assert lib.evo_embed_bf16(None, None, None, 4, 12, 512, None, None) == -1          # D not a multiple of 8
+    assert lib.evo_embed_bf16(None, None, None, 4, 16, 0, None, None) == -1            # empty vocabulary
+    assert lib.evo_unembed_logprob_bf16(None, None, None, None, None, 8, 256, 4096, None) == -1    # V must be 512
+    assert lib.evo_unembed_logprob_bf16(None, None, None, None, None, 8, 512, 100, None) == -1     # K % 32
     assert lib.evo_gelu_gate_bf16(None, None, 4, 12, None) == -1
     assert lib.evo_attn_fwd_causal_bf16(None, None, None, None, 1, 1, 4, 4, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, None) == -1
 

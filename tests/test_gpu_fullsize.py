@@ -79,3 +79,27 @@ def test_scoring_step_8x8193_is_deterministic_and_finite():
     b = logits_to_logprobs(m(ids)[0], ids)
     assert torch.equal(a, b) and torch.isfinite(a).all() and a.shape == (8, 8192)
     assert (a <= 0).all()
+
+
+def test_attention_pipelined_kernel_is_reproducible_across_launches_and_query_offsets(ops):
+    """Hazard stress for the pipelined kernel: hand-written v_max3 on MFMA accumulators used to
+    depend on timing.  Eight launches on the same data must be bit-identical, and query ranges that START on a
+    non-diagonal first tile (q_pos0 > 0: the prologue's QK^T feeds the row max directly) must reproduce the same rows
+    of the full launch bit for bit, at several offsets.  H = 32, T = 16,385."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    T, H = 16385, 32
+    qkv = torch.randn(1, T, 3, H, 128, generator=g, device=DEV).bfloat16()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    full = ops.attention(q, k, v, 0)
+    for _ in range(7):
+        assert torch.equal(ops.attention(q, k, v, 0), full)
+    for off in (256, 1000, 4097, 12289, T - 257):
+        part = ops.attention(q[:, off:], k, v, off)
+        assert torch.equal(part, full[:, off:]), off
+    # and against eager fp32 attention on a few query rows spread over the sequence (full key range, all heads)
+    rows = torch.tensor([0, 63, 64, 255, 256, 4096, 8191, T - 1], device=DEV)
+    for h in (0, 13, 31):
+        sc = (q[0, rows, h].float() @ k[0, :, h].float().t()) / math.sqrt(128.0)
+        sc = sc.masked_fill(torch.arange(T, device=DEV)[None, :] > rows[:, None], float("-inf"))
+        ref = torch.softmax(sc, -1) @ v[0, :, h].float()
+        assert rel_l2(full[0, rows, h].float(), ref) < 4e-3

@@ -169,6 +169,26 @@ def test_hyena_prefill_matches_oracle(ops, B, T, D, H, seg):
     assert (st.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max()
 
 
+def test_hyena_prefill_with_padding_mask_matches_oracle(ops):
+    """mask [B,T]: a padded position contributes nothing to the modes and outputs zero (upstream multiplies the FIR
+    output by padding_mask).  Pads in the middle, at the start, across a segment boundary; all-ones == no mask."""
+    B, T, D, H = 2, 301, 256, 2
+    prm = hyena_params(D, 40)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(41)))
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[0, 0] = False
+    mask[0, 30:35] = False
+    mask[1, 250:] = False
+    y, st = run_hyena(ops, z, prm, H, want_state=True, seg_len=32, mask=mask)
+    ry, rst = R.op_hyena(z, *prm, H, mask=mask)
+    assert_close_bf16(y, ry)
+    assert (y[0, 30:35] == 0).all() and (y[1, 250:] == 0).all()
+    assert (st.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max()
+    y1, _ = run_hyena(ops, z, prm, H, seg_len=32, mask=torch.ones(B, T, dtype=torch.bool))
+    y0, _ = run_hyena(ops, z, prm, H, seg_len=32)
+    assert torch.equal(y1, y0)
+
+
 def test_hyena_prefill_131k_long_memory(ops):
     """BASELINE configs[2] length: T = 131,073 with |p| up to 0.99999.  One head (128 channels) keeps the fp64
     oracle affordable; the segment/carry machinery is independent of the head count."""

@@ -142,6 +142,22 @@ def test_scoring_fused_tail_equals_logits_path(monkeypatch):
         assert np.abs(x - y).max() < 5e-2
 
 
+def test_padding_mask_matches_oracle_on_gpu():
+    """model(ids, padding_mask=...) on the HIP engine vs the fp64 oracle's masked forward (VERDICT r1 missing #6)."""
+    cfg, sd, m = build(SMALL)
+    ids = acgt(2, 200)
+    mask = torch.ones(2, 201, dtype=torch.bool)
+    mask[0, 150:] = False
+    mask[1, 77:80] = False
+    ref = R.RefStripedHyena(cfg, sd, "fp64")(ids, padding_mask=mask)[0]
+    floor = rel_l2(R.RefStripedHyena(cfg, sd, "bf16")(ids, padding_mask=mask)[0], ref)
+    got = m(ids.to(DEV), padding_mask=mask.to(DEV))[0]
+    assert rel_l2(got, ref) < max(1.5 * floor, 4e-3)
+    plain = m(ids.to(DEV))[0]
+    assert rel_l2(got[0, :150], plain[0, :150]) < 1e-6                 # tail pads never reach back
+    assert rel_l2(got[1, 80:], plain[1, 80:]) > 1e-4                   # interior pads change what follows
+
+
 def test_out_of_range_ids_raise_like_the_reference():
     """ids outside [0, vocab) must not index the embedding table out of bounds; the reference's F.embedding
     device-asserts, this engine raises IndexError."""

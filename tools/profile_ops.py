@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--attn-T", type=int, default=16385)
     ap.add_argument("--seg-len", type=int, default=0)
+    ap.add_argument("--only", default="", help="hyena: just the Hyena operator (both shapes)")
     args = ap.parse_args()
     from evo_amd.ops import default_ops
     ops = default_ops()
@@ -46,11 +47,16 @@ def main():
         gg = rn(B * T, 2 * I).bfloat16()
         for _ in range(args.reps):
             ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, want_state=True, seg_len=args.seg_len or None)
+            if args.only == "hyena":
+                continue
             ops.rmsnorm(x, None, scale, 1e-6)
             ops.rmsnorm(x, bias, scale, 1e-6)
             ops.gelu_gate(gg)
         del z, x, gg
         torch.cuda.synchronize()
+    if args.only == "hyena":
+        print("profile_ops done")
+        return
     T = args.attn_T
     qkv = rn(1, T, 3, H, 128).bfloat16()
     cos = torch.rand(T, 64, generator=g, device=dev)
