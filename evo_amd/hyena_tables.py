@@ -1,0 +1,108 @@
+"""Per-channel constant tables of the blocked (matrix-core) form of the Hyena long convolution.
+
+The filter of channel d is a finite sum of modes, h_k = Re sum_s R_s p_s^k.  Time is cut into blocks of L = 32 steps
+and tiles of NB = 16 blocks.  With x = x1*v and S the 8 complex modal states (16 reals, S_t = p S_{t-1} + x_t):
+
+    within a block      y0[i]  = sum_{j<=i} h[i-j] x[j]                      T0 [L x L]  lower-triangular Toeplitz
+    block aggregate     E[m]   = sum_j  (p^(L-1-j))_m x[j]                   W  [16 x L] (m = 2s: re, 2s+1: im)
+    block scan          S_end[a] = p^L S_end[a-1] + E[a]                     P  powers p^(L 2^k), k = 0..3 (Kogge-Stone)
+    carry into a block  yc[i]  = sum_m G[i][m] S_start[m]                    G  [L x 16]:  Re(R p^(i+1)), -Im(R p^(i+1))
+
+T0 and W multiply bf16 data on the bf16 matrix cores, so they are stored as sums of bf16 terms (T0: hi + lo, W: hi + mid +
+lo -- 2^-17 and 2^-25 relative); G and P stay fp32 (fp32 matrix cores / VALU).  Everything is evaluated in fp64 here,
+once per model load, and laid out in the MFMA operand order the kernel reads (csrc/hyena_mfma.hip).  The same numbers
+drive the CPU emulation in tests/test_hyena_blocked.py.
+"""
+from __future__ import annotations
+
+import torch
+
+L = 32          # steps per block  (= K of v_mfma_f32_16x16x32_bf16)
+NB = 16         # blocks per tile  (= N of the 16x16 MFMA tile)
+NS = 8          # modes
+
+
+def _split_bf16(x: torch.Tensor, n: int):
+    """x (fp64) -> n bf16 tensors whose fp64 sum approximates x to 2^-(8n+1) relative."""
+    parts, r = [], x.clone()
+    for _ in range(n):
+        p = r.to(torch.float32).to(torch.bfloat16)
+        parts.append(p)
+        r = r - p.to(torch.float64)
+    return parts
+
+
+def blocked_constants(poles: torch.Tensor, residues: torch.Tensor):
+    """poles, residues [D, 8, 2] fp32 -> dict of per-channel constants (math layout):
+         T0 [2][D, L, L] bf16 (hi, lo)      W [3][D, 16, L] bf16 (hi, mid, lo)
+         G [D, L, 16] f32                   P [D, 4, 16] f32: (re, im) of p_s^(L 2^k) as [k][2s], [k][2s+1]"""
+    D = poles.shape[0]
+    p = torch.view_as_complex(poles.double().contiguous())            # [D, 8]
+    r = torch.view_as_complex(residues.double().contiguous())
+    k = torch.arange(L + 1, dtype=torch.float64, device=poles.device)
+    # integer powers by cumulative product in fp64 (exact enough: 33 steps)
+    pw = torch.ones(D, NS, L + 1, dtype=torch.complex128, device=poles.device)
+    for i in range(1, L + 1):
+        pw[..., i] = pw[..., i - 1] * p
+    h = (r[..., None] * pw[..., :L]).real.sum(1)                      # [D, L]  h_k, k < L
+    idx = torch.arange(L, device=poles.device)
+    lag = idx[:, None] - idx[None, :]                                 # i - j
+    T0 = torch.where(lag[None] >= 0, h[:, lag.clamp_min(0)], torch.zeros((), dtype=torch.float64, device=poles.device))
+    Wc = pw[..., :L].flip(-1)                                         # [D, 8, L]: p^(L-1-j)
+    W = torch.stack([Wc.real, Wc.imag], 2).reshape(D, 2 * NS, L)      # m = 2s (re), 2s+1 (im)
+    Gc = r[..., None] * pw[..., 1:L + 1]                              # [D, 8, L]: R p^(i+1)
+    G = torch.stack([Gc.real, -Gc.imag], 2).reshape(D, 2 * NS, L).transpose(1, 2).contiguous()   # [D, L, 16]
+    P = []
+    q = pw[..., L]                                                    # p^L
+    for _ in range(4):
+        P.append(torch.stack([q.real, q.imag], -1).reshape(D, 2 * NS))
+        q = q * q
+    P = torch.stack(P, 1)                                             # [D, 4, 16]
+    return {"T0": _split_bf16(T0, 2), "W": _split_bf16(W, 3), "G": G.float(), "P": P.float(), "h": h}
+
+
+# ---- MFMA operand order -------------------------------------------------------------------------------------------------
+# One table row per channel: 52 dwords per lane x 64 lanes, in the order csrc/hyena_mfma.hip keeps them in registers.
+#   v_mfma_f32_16x16x32_bf16  A operand: lane l holds A[row = l & 15][k = 8 (l >> 4) + 0..7]  (4 dwords = 8 bf16)
+#   v_mfma_f32_16x16x4_f32    A operand: lane l holds A[row = l & 15][k = l >> 4]             (1 dword)
+#   (B operands come from the data; C/D: lane l holds D[row = 4 (l >> 4) + r][col = l & 15], r = 0..3)
+TAB_T0 = 0          # [mt 2][split 2][4 dwords]   T0[16 mt + row][k]
+TAB_W = 16          # [split 3][4 dwords]         W[row = m][k = j]
+TAB_P = 28          # [k 4][r 4]                  P[k][4 q + r],  q = l >> 4 (the lane's two modes: re, im, re, im)
+TAB_G = 44          # [mt 2][ks 4]                G[16 mt + row][m = 4 (l >> 4) + ks]
+TAB_WORDS = 52
+
+
+def _pack_bf16_pairs(x: torch.Tensor) -> torch.Tensor:
+    """[..., 2n] bf16 -> [..., n] int32, low half = even element."""
+    u = x.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    return (u[..., 0::2] | (u[..., 1::2] << 16)).to(torch.int32)
+
+
+def mfma_operand_table(poles: torch.Tensor, residues: torch.Tensor) -> torch.Tensor:
+    """[D, 52, 64] int32: the per-lane constant registers of every channel (13,312 B per channel)."""
+    C = blocked_constants(poles, residues)
+    D = poles.shape[0]
+    dev = poles.device
+    lane = torch.arange(64, device=dev)
+    row, kg = lane & 15, lane >> 4
+    tab = torch.empty(D, TAB_WORDS, 64, dtype=torch.int32, device=dev)
+    kk = (8 * kg)[:, None] + torch.arange(8, device=dev)[None, :]                 # [64, 8] k indices of a bf16 A fragment
+    for mt in range(2):
+        for sp in range(2):
+            frag = C["T0"][sp][:, (16 * mt + row)[:, None], kk]                   # [D, 64, 8] bf16
+            base = TAB_T0 + (mt * 2 + sp) * 4
+            tab[:, base:base + 4, :] = _pack_bf16_pairs(frag).transpose(1, 2)
+    for sp in range(3):
+        frag = C["W"][sp][:, row[:, None], kk]                                    # [D, 64, 8]
+        base = TAB_W + sp * 4
+        tab[:, base:base + 4, :] = _pack_bf16_pairs(frag).transpose(1, 2)
+    P = C["P"]                                                                    # [D, 4, 16]
+    for k in range(4):
+        for r in range(4):
+            tab[:, TAB_P + 4 * k + r, :] = P[:, k, 4 * kg + r].contiguous().view(torch.int32)
+    G = C["G"]                                                                    # [D, L, 16]
+    for mt in range(2):
+        for ks in range(4):
+            tab[:, TAB_G + 4 * mt + ks, :] = G[:, 16 * mt + row, 4 * kg + ks].contiguous().view(torch.int32)
+    return tab.contiguous()

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_unembed_logprob_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_hyena_mfma": ([_PTR] * 7 + [_I64] * 4 + [_PTR], _c.c_int),
 }
 
 _LIB = None
@@ -159,6 +160,7 @@ class HipOps:
         self.attn_gemm_mfma = os.environ.get("EVO_AMD_ATTN_GEMM", "mfma").lower() != "hipblaslt"
         self.timer: Optional[KernelTimer] = None
         self.validate_ids = os.environ.get("EVO_AMD_VALIDATE_IDS", "1") != "0"   # one 4-byte D2H read per forward
+        self.hyena_mfma = os.environ.get("EVO_AMD_HYENA", "mfma").lower() != "modal"   # single-pass matrix-core operator
         self.last_hyena_io = {}
 
     def _t(self, name):
@@ -318,9 +320,15 @@ class HipOps:
                       residues: torch.Tensor, dskip: torch.Tensor, n_heads: int,
                       z_halo: Optional[torch.Tensor] = None, s0: Optional[torch.Tensor] = None,
                       want_state: bool = False, seg_len: Optional[int] = None,
-                      mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                      mask: Optional[torch.Tensor] = None, table: Optional[torch.Tensor] = None
+                      ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """z [B,T,3D] bf16 -> y [B,T,D] bf16 (+ complex64 state [B,D,8] after the last token).  `mask` [B,T] (bool /
-        uint8, 1 = token) is upstream's padding_mask: padded positions get a zero FIR output."""
+        uint8, 1 = token) is upstream's padding_mask: padded positions get a zero FIR output.  `table` (the layer's
+        hyena_tables.mfma_operand_table) enables the single-pass matrix-core kernel for plain scoring shapes (no
+        carry-in, no end state, no mask); everything else takes the three-launch modal form."""
+        if (table is not None and self.hyena_mfma and s0 is None and mask is None and not want_state and seg_len is None
+                and z.shape[2] == 3 * n_heads * 128):
+            return self.hyena_mfma_prefill(z, fir_w, fir_b, dskip, table, n_heads, z_halo), None
         if mask is not None:
             mask = mask.to(device=z.device, dtype=torch.uint8).contiguous()
             assert mask.shape == z.shape[:2]
@@ -360,6 +368,25 @@ class HipOps:
         self.last_hyena_io = {"seg_state": z.numel() * 2 * 2 // 3 + agg.numel() * 4,
                               "apply": z.numel() * 2 + y.numel() * 2 + agg.numel() * 4}
         return y, state
+
+    def hyena_mfma_prefill(self, z, fir_w, fir_b, dskip, table, n_heads, z_halo=None) -> torch.Tensor:
+        """Single-pass matrix-core Hyena operator (csrc/hyena_mfma.hip): z [B,T,3D] bf16 -> y [B,T,D] bf16."""
+        self._need(z, torch.bfloat16, "hyena z")
+        B, T, D3 = z.shape
+        D = D3 // 3
+        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b"), (dskip, "dskip")):
+            self._need(t, torch.bfloat16, "hyena " + nm)
+        if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
+            raise RuntimeError("hyena_mfma: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
+        if z_halo is not None:
+            self._need(z_halo, torch.bfloat16, "hyena z_halo")
+            assert z_halo.shape == (B, 2, D3)
+        y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
+        with self._t("hyena_mfma"):
+            _check(self.lib.evo_hyena_mfma(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(),
+                                           table.data_ptr(), y.data_ptr(), B, T, D, n_heads, _stream()), "evo_hyena_mfma")
+        self.last_hyena_io = {"mfma": z.numel() * 2 + y.numel() * 2}
+        return y
 
     # The same operator in two stages, for sequence parallelism: stage 1 (launches 1+2) yields the shard's end
     # state from a ZERO carry-in; after the ranks exchange those, stage 2 (carry-add + launch 3) finishes.

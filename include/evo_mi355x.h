@@ -26,7 +26,7 @@ extern "C" {
 
 /* ABI version; bumped when a signature changes (the binding refuses a library whose version differs).
  *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_seg_state / evo_hyena_apply gained `mask`;
- *      evo_unembed_logprob_bf16 added. */
+ *      evo_unembed_logprob_bf16 and evo_hyena_mfma added. */
 #define EVO_ABI_VERSION 2
 int evo_abi_version(void);
 
@@ -86,6 +86,19 @@ int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const 
                     const float* poles, const float* residues, const void* dskip,
                     const float* agg, void* y, const uint8_t* mask,
                     int64_t B, int64_t T, int64_t D, int64_t n_heads, int64_t seg_len, void* stream);
+
+/* ---- Hyena operator, single-pass matrix-core form (scoring fast path) -------------------------------
+ * replaces the same reference functions as the three launches above (parallel_fir + compute_filter +
+ * parallel_iir)                                            [REF evo/configs/evo-1-8k-base_inference.yml:8,10,14,33,37]
+ * One launch, z read once, y written once: a workgroup owns 16 channels of one batch row and walks the
+ * sequence in tiles of 512 steps; per tile the long convolution is a block-Toeplitz product + block
+ * aggregates on v_mfma_f32_16x16x32_bf16 (bf16-split operands, fp32 accumulation), a Kogge-Stone scan of the
+ * 16 blocks' modal states in fp32, and the carry product on v_mfma_f32_16x16x4_f32 (csrc/hyena_mfma.hip).
+ *   table [D, 52, 64] u32: per-channel MFMA operand constants (evo_amd/hyena_tables.py: mfma_operand_table)
+ *   z_halo as above; no carry-in state, end state or mask (those shapes take the three-launch form).
+ * D = n_heads * 128 (any B, T). */
+int evo_hyena_mfma(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* dskip,
+                   const void* table, void* y, int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
  * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]

@@ -169,6 +169,48 @@ def test_hyena_prefill_matches_oracle(ops, B, T, D, H, seg):
     assert (st.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max()
 
 
+@pytest.mark.parametrize("B,T,D,H", [
+    (2, 37, 128, 1),             # one ragged tile
+    (1, 1, 128, 1),              # single token
+    (2, 513, 256, 2),            # a full tile + 1 row: the tile-to-tile carry
+    (1, 513, 4096, 32),          # BASELINE configs[0] length at the real width
+    (2, 8193, 256, 2),           # BASELINE configs[1] length: 17 tiles
+    (1, 3000, 128, 1),
+])
+def test_hyena_mfma_single_pass_matches_oracle(ops, B, T, D, H):
+    """evo_hyena_mfma (block Toeplitz + aggregates on bf16 MFMA, fp32 block scan, carry on fp32 MFMA) vs the fp64
+    oracle, and vs the three-launch modal kernels on the same data."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    prm = hyena_params(D, 60)
+    fir_w, fir_b, poles, res, dskip = prm
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(61)))
+    tab = mfma_operand_table(poles.to(DEV), res.to(DEV))
+    y, st = run_hyena(ops, z, prm, H, table=tab)
+    assert st is None
+    ry, _ = R.op_hyena(z, *prm, H)
+    assert_close_bf16(y, ry, rl2=2e-3 if y.numel() > 4096 else 3.5e-3)      # (few outputs: the rel-L2 estimate is noisy)
+    y_modal, _ = run_hyena(ops, z, prm, H)
+    assert rel_l2(y, y_modal) < 2.5e-3
+    if T > 4:                                                          # with a halo (sequence-parallel / resumed shard)
+        cut = max(2, T // 3)
+        yb, _ = run_hyena(ops, z[:, cut:].contiguous(), prm, H, table=tab, z_halo=z[:, cut - 2:cut].contiguous())
+        ya = R.op_hyena(z[:, cut:], *prm, H, z_halo=z[:, cut - 2:cut])[0]
+        assert_close_bf16(yb, ya)
+
+
+def test_hyena_mfma_131k_long_memory(ops):
+    """T = 131,073 with |p| up to 0.99999: 257 sequential tiles of carried fp32 state (one head keeps the fp64 oracle
+    affordable)."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    B, T, D, H = 1, 131073, 128, 1
+    prm = hyena_params(D, 62)
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(63)))
+    tab = mfma_operand_table(prm[2].to(DEV), prm[3].to(DEV))
+    y, _ = run_hyena(ops, z, prm, H, table=tab)
+    ry, _ = R.op_hyena(z, *prm, H)
+    assert_close_bf16(y, ry)
+
+
 def test_hyena_prefill_with_padding_mask_matches_oracle(ops):
     """mask [B,T]: a padded position contributes nothing to the modes and outputs zero (upstream multiplies the FIR
     output by padding_mask).  Pads in the middle, at the start, across a segment boundary; all-ones == no mask."""

@@ -49,6 +49,21 @@ def main():
             print(f"[{tag}] hyena B={B} T={T} seg={args.seg_len or 'auto'}: " +
                   " ".join(f"{k.replace('hyena_', '')}={v[1]:.3f}ms" for k, v in s.items()) +
                   f" | apply {alg / s['hyena_apply'][1] / 1e6:.0f} GB/s, operator {alg / tot / 1e6:.0f} GB/s")
+            try:                                                   # single-pass matrix-core form of the same operator
+                from evo_amd.hyena_tables import mfma_operand_table
+                tab = mfma_operand_table(poles, res)
+                for _ in range(2):
+                    ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, table=tab)
+                ops.timer = KernelTimer()
+                for _ in range(args.reps):
+                    ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, table=tab)
+                torch.cuda.synchronize()
+                ms = ops.timer.summary()["hyena_mfma"][1]
+                ops.timer = None
+                print(f"[{tag}] hyena_mfma B={B} T={T}: {ms:.3f}ms | {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of 8 TB/s")
+            except Exception as e:  # noqa: BLE001
+                ops.timer = None
+                print(f"[{tag}] hyena_mfma B={B} T={T}: FAILED {type(e).__name__}: {e}")
             del z
     if args.only in ("", "attn"):
         for T in (8193, args.attn_T):
