@@ -9,7 +9,9 @@ and tiles of NB = 16 blocks.  With x = x1*v and S the 8 complex modal states (16
     carry into a block  yc[i]  = sum_m G[i][m] S_start[m]                    G  [L x 16]:  Re(R p^(i+1)), -Im(R p^(i+1))
 
 T0 and W multiply bf16 data on the bf16 matrix cores, so they are stored as sums of bf16 terms (T0: hi + lo, W: hi + mid +
-lo -- 2^-17 and 2^-25 relative); G and P stay fp32 (fp32 matrix cores / VALU).  Everything is evaluated in fp64 here,
+lo -- 2^-17 and 2^-25 relative).  G multiplies the fp32 block states: both are split hi + lo in bf16 (the kernel splits the
+states on the fly), G_hi S_hi + G_hi S_lo + G_lo S_hi on the bf16 matrix cores (2^-17; the fp32 matrix cores would be exact
+but 8x slower per product).  P stays fp32 (VALU).  Everything is evaluated in fp64 here,
 once per model load, and laid out in the MFMA operand order the kernel reads (csrc/hyena_mfma.hip).  The same numbers
 drive the CPU emulation in tests/test_hyena_blocked.py.
 """
@@ -32,8 +34,9 @@ def _split_bf16(x: torch.Tensor, n: int):
     return parts
 
 
-def blocked_constants(poles: torch.Tensor, residues: torch.Tensor):
-    """poles, residues [D, 8, 2] fp32 -> dict of per-channel constants (math layout):
+def blocked_constants(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.Tensor = None):
+    """poles, residues [D, 8, 2] fp32 (+ dskip [D]: filter.D, added to T0's diagonal so that T0 . X = y_conv + x1v * D within
+    a block -- the skip term costs nothing) -> dict of per-channel constants (math layout):
          T0 [2][D, L, L] bf16 (hi, lo)      W [3][D, 16, L] bf16 (hi, mid, lo)
          G [D, L, 16] f32                   P [D, 4, 16] f32: (re, im) of p_s^(L 2^k) as [k][2s], [k][2s+1]"""
     D = poles.shape[0]
@@ -48,6 +51,8 @@ def blocked_constants(poles: torch.Tensor, residues: torch.Tensor):
     idx = torch.arange(L, device=poles.device)
     lag = idx[:, None] - idx[None, :]                                 # i - j
     T0 = torch.where(lag[None] >= 0, h[:, lag.clamp_min(0)], torch.zeros((), dtype=torch.float64, device=poles.device))
+    if dskip is not None:
+        T0 = T0 + torch.diag_embed(dskip.to(torch.float64)[:, None].expand(D, L))
     Wc = pw[..., :L].flip(-1)                                         # [D, 8, L]: p^(L-1-j)
     W = torch.stack([Wc.real, Wc.imag], 2).reshape(D, 2 * NS, L)      # m = 2s (re), 2s+1 (im)
     Gc = r[..., None] * pw[..., 1:L + 1]                              # [D, 8, L]: R p^(i+1)
@@ -58,18 +63,20 @@ def blocked_constants(poles: torch.Tensor, residues: torch.Tensor):
         P.append(torch.stack([q.real, q.imag], -1).reshape(D, 2 * NS))
         q = q * q
     P = torch.stack(P, 1)                                             # [D, 4, 16]
-    return {"T0": _split_bf16(T0, 2), "W": _split_bf16(W, 3), "G": G.float(), "P": P.float(), "h": h}
+    return {"T0": _split_bf16(T0, 2), "W": _split_bf16(W, 3), "G": G.float(), "Gs": _split_bf16(G, 2), "P": P.float(), "h": h}
 
 
 # ---- MFMA operand order -------------------------------------------------------------------------------------------------
 # One table row per channel: 52 dwords per lane x 64 lanes, in the order csrc/hyena_mfma.hip keeps them in registers.
 #   v_mfma_f32_16x16x32_bf16  A operand: lane l holds A[row = l & 15][k = 8 (l >> 4) + 0..7]  (4 dwords = 8 bf16)
-#   v_mfma_f32_16x16x4_f32    A operand: lane l holds A[row = l & 15][k = l >> 4]             (1 dword)
 #   (B operands come from the data; C/D: lane l holds D[row = 4 (l >> 4) + r][col = l & 15], r = 0..3)
 TAB_T0 = 0          # [mt 2][split 2][4 dwords]   T0[16 mt + row][k]
 TAB_W = 16          # [split 3][4 dwords]         W[row = m][k = j]
-TAB_P = 28          # [k 4][r 4]                  P[k][4 q + r],  q = l >> 4 (the lane's two modes: re, im, re, im)
-TAB_G = 44          # [mt 2][ks 4]                G[16 mt + row][m = 4 (l >> 4) + ks]
+TAB_G = 28          # [mt 2][4 dwords]            carry product, K = 32: per k-group kg the B operand is [S_hi(4 kg .. 4 kg + 3) | S_lo(same)]
+                    #                             words: G_hi(row, 4 kg + {0,1}), G_hi(.. {2,3}), G_lo(.. {0,1}), G_lo(.. {2,3}); the kernel
+                    #                             forms the A operands [G_hi | G_hi] and [G_lo | 0] from them
+TAB_P = 36          # [k 4][r 4]                  P[k][4 q + r],  q = l >> 4 (the lane's two modes: re, im, re, im);
+                    #                             the kernel keeps these 16 words in LDS, not in registers
 TAB_WORDS = 52
 
 
@@ -79,9 +86,10 @@ def _pack_bf16_pairs(x: torch.Tensor) -> torch.Tensor:
     return (u[..., 0::2] | (u[..., 1::2] << 16)).to(torch.int32)
 
 
-def mfma_operand_table(poles: torch.Tensor, residues: torch.Tensor) -> torch.Tensor:
-    """[D, 52, 64] int32: the per-lane constant registers of every channel (13,312 B per channel)."""
-    C = blocked_constants(poles, residues)
+def mfma_operand_table(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.Tensor) -> torch.Tensor:
+    """[D, 52, 64] int32: the per-lane constant registers of every channel (13,312 B per channel); filter.D is folded into
+    the block-Toeplitz diagonal."""
+    C = blocked_constants(poles, residues, dskip)
     D = poles.shape[0]
     dev = poles.device
     lane = torch.arange(64, device=dev)
@@ -101,8 +109,30 @@ def mfma_operand_table(poles: torch.Tensor, residues: torch.Tensor) -> torch.Ten
     for k in range(4):
         for r in range(4):
             tab[:, TAB_P + 4 * k + r, :] = P[:, k, 4 * kg + r].contiguous().view(torch.int32)
-    G = C["G"]                                                                    # [D, L, 16]
+    Gh, Gl = C["Gs"]                                                              # [D, L, 16] bf16
+    cc = (4 * kg)[:, None] + torch.arange(4, device=dev)[None, :]                 # [64, 4] components of the lane's k-group
     for mt in range(2):
-        for ks in range(4):
-            tab[:, TAB_G + 4 * mt + ks, :] = G[:, 16 * mt + row, 4 * kg + ks].contiguous().view(torch.int32)
+        gh = Gh[:, (16 * mt + row)[:, None], cc]                                  # [D, 64, 4]
+        gl = Gl[:, (16 * mt + row)[:, None], cc]
+        base = TAB_G + 4 * mt
+        tab[:, base:base + 4, :] = _pack_bf16_pairs(torch.cat([gh, gl], -1)).transpose(1, 2)
     return tab.contiguous()
+
+
+# ---- grouped z layout ------------------------------------------------------------------------------------------------------
+GROUP = 16      # channels per workgroup of csrc/hyena_mfma.hip
+
+
+def group_permutation(D: int, n_heads: int, device=None) -> torch.Tensor:
+    """perm [3D] int64: grouped column r = cg * 48 + g * 16 + j  <-  reference column  c = h * 3 hd + g * hd + (cg % (hd/16)) * 16 + j
+    (h = cg // (hd / 16), hd = D / n_heads, g in {0: x2, 1: x1, 2: v}).  `z_grouped = z[..., perm]`; applied once to the ROWS
+    of the projection weight / bias, the GEMM writes the grouped layout directly and the 96 bytes a workgroup needs of a z
+    row are contiguous."""
+    hd = D // n_heads
+    gph = hd // GROUP
+    cg = torch.arange(D // GROUP, device=device)
+    g = torch.arange(3, device=device)
+    j = torch.arange(GROUP, device=device)
+    h = cg // gph
+    c = (h * 3 * hd)[:, None, None] + (g * hd)[None, :, None] + ((cg % gph) * GROUP)[:, None, None] + j[None, None, :]
+    return c.reshape(-1)

@@ -328,7 +328,12 @@ class HipOps:
         carry-in, no end state, no mask); everything else takes the three-launch modal form."""
         if (table is not None and self.hyena_mfma and s0 is None and mask is None and not want_state and seg_len is None
                 and z.shape[2] == 3 * n_heads * 128):
-            return self.hyena_mfma_prefill(z, fir_w, fir_b, dskip, table, n_heads, z_halo), None
+            # (test / tool convenience: the product hands the matrix-core kernel a z the projection GEMM already wrote
+            #  in the grouped layout -- see StripedHyena._hyena_block)
+            from .hyena_tables import group_permutation
+            perm = group_permutation(z.shape[2] // 3, n_heads, z.device)
+            halo_g = None if z_halo is None else z_halo[..., perm].contiguous()
+            return self.hyena_mfma_prefill(z[..., perm].contiguous(), fir_w, fir_b, dskip, table, n_heads, halo_g), None
         if mask is not None:
             mask = mask.to(device=z.device, dtype=torch.uint8).contiguous()
             assert mask.shape == z.shape[:2]
@@ -370,7 +375,8 @@ class HipOps:
         return y, state
 
     def hyena_mfma_prefill(self, z, fir_w, fir_b, dskip, table, n_heads, z_halo=None) -> torch.Tensor:
-        """Single-pass matrix-core Hyena operator (csrc/hyena_mfma.hip): z [B,T,3D] bf16 -> y [B,T,D] bf16."""
+        """Single-pass matrix-core Hyena operator (csrc/hyena_mfma.hip): z [B,T,3D] bf16 in the GROUPED column layout
+        (hyena_tables.group_permutation; fir_w / fir_b / dskip stay in the reference's channel order) -> y [B,T,D] bf16."""
         self._need(z, torch.bfloat16, "hyena z")
         B, T, D3 = z.shape
         D = D3 // 3

@@ -1,6 +1,6 @@
 """CPU: the blocked (matrix-core) form of the Hyena long convolution -- block Toeplitz + block aggregates + Kogge-Stone
 block scan + carry product, with the kernel's operand precisions (bf16 hi/lo data, bf16-split T0 / W, fp32 G / P, fp32
-accumulation) -- emulated in torch and compared with the fp64 oracle.  This pins the MATH and the PRECISION of
+accumulation; the carry product G . S with both operands bf16-split) -- emulated in torch and compared with the fp64 oracle.  This pins the MATH and the PRECISION of
 csrc/hyena_mfma.hip (constants from evo_amd/hyena_tables.py) independently of any GPU layout question."""
 import math
 
@@ -17,7 +17,7 @@ def emulate_blocked(z, fir_w, fir_b, poles, residues, dskip, H):
     D = D3 // 3
     hd = D // H
     L, NB = HT.L, HT.NB
-    C = HT.blocked_constants(poles, residues)
+    C = HT.blocked_constants(poles, residues, dskip)                         # filter.D rides on T0's diagonal
     f32 = torch.float32
     # FIR + bias in fp32 (as the kernel: three fp32 FMAs on bf16 inputs)
     zt = torch.nn.functional.pad(z.to(f32).transpose(1, 2), (2, 0))            # [B,3D,T+2]
@@ -37,7 +37,8 @@ def emulate_blocked(z, fir_w, fir_b, poles, residues, dskip, H):
     xh, xl = x_hi.to(f32), x_lo.to(f32)
     T0h, T0l = (t.to(f32) for t in C["T0"])                                     # [D,L,L]
     Wh, Wm, Wl = (t.to(f32) for t in C["W"])                                    # [D,16,L]
-    G, P = C["G"], C["P"]                                                       # [D,L,16], [D,4,16]
+    P = C["P"]                                                                  # [D,4,16]
+    Gh, Gl = (t.to(f32) for t in C["Gs"])                                       # [D,L,16] bf16 hi / lo of G
     # block Toeplitz and aggregates: exact bf16 products, fp32 accumulation (einsum in fp32)
     y0 = torch.einsum("dij,bdtaj->bdtai", T0h, xh) + torch.einsum("dij,bdtaj->bdtai", T0h, xl) \
         + torch.einsum("dij,bdtaj->bdtai", T0l, xh)
@@ -66,11 +67,14 @@ def emulate_blocked(z, fir_w, fir_b, poles, residues, dskip, H):
             sh[:, :, d:] = S[:, :, :-d]
             S = cmul_add(S, P[None, :, k, None], sh)
         S_start = torch.cat([carry[:, :, None], S[:, :, :-1]], 2)               # state entering each block
-        yc = torch.einsum("dim,bdam->bdai", G, S_start)
+        Sh = S_start.to(torch.bfloat16).to(f32)                                 # the kernel splits the states hi + lo in bf16
+        Sl = (S_start - Sh).to(torch.bfloat16).to(f32)
+        yc = torch.einsum("dim,bdam->bdai", Gh, Sh) + torch.einsum("dim,bdam->bdai", Gh, Sl) \
+            + torch.einsum("dim,bdam->bdai", Gl, Sh)
         y[:, :, t] = y0[:, :, t] + yc
         carry = S[:, :, -1]
     yconv = y.reshape(B, D, nt * TT)[..., :T]
-    out = (yconv + x * dskip.to(f32)[None, :, None]) * x2
+    out = yconv * x2                                                            # yconv already holds y + x1v * D
     return out.transpose(1, 2).contiguous(), yconv
 
 

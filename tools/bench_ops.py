@@ -51,12 +51,12 @@ def main():
                   f" | apply {alg / s['hyena_apply'][1] / 1e6:.0f} GB/s, operator {alg / tot / 1e6:.0f} GB/s")
             try:                                                   # single-pass matrix-core form of the same operator
                 from evo_amd.hyena_tables import mfma_operand_table
-                tab = mfma_operand_table(poles, res)
-                for _ in range(2):
-                    ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, table=tab)
+                tab = mfma_operand_table(poles, res, dskip)
+                for _ in range(2):                                     # (random data: the column order does not matter here)
+                    ops.hyena_mfma_prefill(z, fir_w, fir_b, dskip, tab, H)
                 ops.timer = KernelTimer()
                 for _ in range(args.reps):
-                    ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, table=tab)
+                    ops.hyena_mfma_prefill(z, fir_w, fir_b, dskip, tab, H)
                 torch.cuda.synchronize()
                 ms = ops.timer.summary()["hyena_mfma"][1]
                 ops.timer = None
