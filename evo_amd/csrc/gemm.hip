@@ -285,6 +285,317 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(GemmArgs a) {
     }
 }
 
+
+// ================================================================================================================
+// PERSISTENT 4-wave form (the default).  One workgroup per CU walks a list of output tiles; the (tile, k-step) pairs
+// form ONE stream of stages that flows through the five-slot LDS ring without a break, so the next tile's first operands
+// are in flight while the current tile finishes and its epilogue runs (the one-tile-per-workgroup kernel above spends
+// 26-40 k of its ~190 k cycles per tile on launch, pipeline fill and epilogue with the MFMA pipe idle).
+// Wave (wm, wn) of a 2 x 2 grid owns 128(M) x 128(N) = 8 x 8 tiles of v_mfma_f32_16x16x32_bf16; the 256 accumulator
+// registers live in the AGPR half of the unified register file (one wave per SIMD -> 512 registers per lane); per 32-deep
+// half step a wave reads 8 + 8 fragments for 64 MFMAs.  (16x16x32 moves 4x fewer accumulator bytes per flop than 32x32x16:
+// at equal cycle counts the 32x32x16 form of this loop clocked 1.57 GHz where hipBLASLt's 16x16x32 loop clocks 1.69.)
+// With ONE wave per SIMD nothing hides a stalled wave, so the loop is written gap by gap (gap = the slot behind one MFMA,
+// 128 per k-step), at most one memory instruction per gap.  Measured next to back-to-back v_mfma_f32_32x32x16_bf16
+// (tools/probes/mfma_issue_probe.hip, profiles/r02_gemm_notes.txt): a ds_read_b128, SALU or VALU instruction per gap is
+// free; a 16-byte-per-lane global load INTO REGISTERS costs ~24 cycles of MFMA issue each and a ds_write_b128 ~11 (the
+// global -> VGPR -> LDS form of this loop ran at 38.5 instead of 32 cycles per MFMA); an LDS-DMA load costs the same
+// when its M0 write (+ s_nop) sits in the same gap -- and ~6 cycles when M0 is written one gap earlier.  Hence:
+// operands come by buffer_load_dwordx4 ... lds (resource = whole matrix, voffset = lane's row/granule, soffset = tile +
+// k; rows past the end read as zeros, so the ragged last M tile needs no clamping), M0 is set in the preceding odd gap,
+// fragment reads sit in the even gaps.
+// Epilogue scratch: after the barrier of a tile's last k-step the slot of its last W slab is dead until this very wave
+// refills it in the next k-step -- each wave transposes through exactly the eight 1-KiB pieces it will DMA into (one
+// 32-column strip of its tile at a time, rows of 64 B, XOR-swizzled), so no barrier is needed.
+#ifndef GR_PROFILE
+#define GR_PROFILE 0                         // 1: wave 0 of workgroup 0 accumulates cycles per loop segment, written over y (tools/gemm_stage_profile.py)
+#endif
+
+template <bool BIAS, bool RES>
+__global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G_NSLOT * G_SLAB];   // the ONLY __shared__ object
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                     // 2 x 2 wave grid
+    const uint32_t kb = (uint32_t)a.K * 2;                       // bytes per operand row
+    const int nk = a.K / GBK;
+
+    // ---- this workgroup's tiles.  Block b runs on XCD b % 8; every XCD owns a contiguous run of (group_m-rastered) tile
+    //      ids and its workgroups take them round-robin, so the tiles an XCD computes at one time are consecutive ids.
+    int t_first, t_step, n_my;
+    {
+        const int bid = blockIdx.x, per = gridDim.x >> 3;        // host: gridDim.x % 8 == 0
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = a.n_tiles >> 3, r = a.n_tiles & 7;
+        const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int xn = q + (xcd < r ? 1 : 0);
+        t_first = xs + slot;
+        t_step = per;
+        n_my = slot < xn ? (xn - slot + per - 1) / per : 0;
+    }
+    if (n_my == 0) return;
+    auto tile_origin = [&](int tile, int64_t& m0, int& n0) {
+        const int per_group = a.group_m * a.tiles_n;
+        const int grp = tile / per_group, in_grp = tile - grp * per_group;
+        const int first_m = grp * a.group_m;
+        const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
+        const int tn = in_grp / gsz;
+        m0 = (int64_t)(first_m + in_grp - tn * gsz) * GBM;
+        n0 = tn * GBN;
+    };
+
+    // ---- DMA plan: a slab is 32 one-KiB pieces (8 rows of 128 B each); wave w moves pieces w, w + 4, ..., w + 28.  The LDS
+    //      side of a DMA is lane-linear (M0 + 16 lane), so the swizzle is applied to the source: the lane that fills granule
+    //      slot s of row r fetches granule s ^ (r & 7) of that row (a fragment read touches 16 consecutive rows x 4 granules:
+    //      8 consecutive rows hit 8 different slots = all 32 banks).  Rows of one lane are 32 apart: same swizzle term.
+    const int r0 = 8 * wave + (lane >> 3);
+    const uint32_t voff0 = (uint32_t)r0 * kb + (uint32_t)((((lane & 7) ^ r0) & 7) * 16);
+    const uint32_t row32 = 32u * kb;                             // voffset of piece jj = voff0 + jj * row32
+    uint32_t voff[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) voff[jj] = voff0 + jj * row32;
+    const uint64_t xa64 = (uint64_t)a.x, wa64 = (uint64_t)a.w;
+    const g_u32x4 rx = {(uint32_t)xa64, (uint32_t)(xa64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.M * kb), 0x00020000u};
+    const g_u32x4 rw = {(uint32_t)wa64, (uint32_t)(wa64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.N * kb), 0x00020000u};
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t lds_dma = lds0 + wave * 1024;                 // + slot * G_SLAB + jj * 4096
+
+    // fetch cursor: the stage whose slabs are issued next (soffsets: tile origin + k * 128 bytes)
+    int f_i = 0, f_k = 0;
+    uint32_t fxs, fws;
+    {
+        int64_t m0; int n0;
+        tile_origin(t_first, m0, n0);
+        fxs = (uint32_t)(m0 * kb);
+        fws = (uint32_t)n0 * kb;
+    }
+    auto fetch_advance = [&]() {                                 // past the last stage: stay (harmless re-fetches keep the counts constant)
+        if (f_k + 1 < nk) { ++f_k; fxs += GBK * 2; fws += GBK * 2; }
+        else if (f_i + 1 < n_my) {
+            ++f_i; f_k = 0;
+            int64_t m0; int n0;
+            tile_origin(t_first + f_i * t_step, m0, n0);
+            fxs = (uint32_t)(m0 * kb);
+            fws = (uint32_t)n0 * kb;
+        }
+    };
+#define GD_M0(V) asm volatile("s_mov_b32 m0, %0" ::"s"(V) : "memory", "m0")
+#define GD_DMAX(JJ) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[JJ]), "s"(rx), "s"(fxs) : "memory")
+#define GD_DMAW(JJ) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[JJ]), "s"(rw), "s"(fws) : "memory")
+
+    // fragment bases (within a slab): v_mfma_f32_16x16x32_bf16 operands -- lane (row = l & 15, kg = l >> 4) holds the 8 bf16
+    // k = 32 kh + 8 kg .. + 7 of its row.  A operand = W rows (n), B operand = X rows (m): D[n][m], a lane's four accumulator
+    // registers run along n.  Tiles 16 rows apart share (row & 7): one base per k-half, tile offsets are immediates.
+    const int l15 = lane & 15, lq = lane >> 4;
+    uint32_t x_rd[2], w_rd[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int xr = wm * 128 + l15, wr = wn * 128 + l15;
+        x_rd[kh] = lds0 + (uint32_t)(xr * G_ROW + (((4 * kh + lq) ^ xr) & 7) * 16);
+        w_rd[kh] = lds0 + (uint32_t)(wr * G_ROW + (((4 * kh + lq) ^ wr) & 7) * 16);
+    }
+
+    f32x4_t acc[8][8];                                           // [n tile][m tile]
+#define GR_ZERO()                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 8; ++j)               \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    GR_ZERO();
+    asm volatile("s_nop 7" ::: "memory");
+    g_u32x4 wf[2][8], xf[2][8];                                  // double-buffered fragments of one k-half
+
+#define GR_LGKM(N, BUF)                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(wf[BUF][0]), "+v"(wf[BUF][1]), "+v"(wf[BUF][2]), "+v"(wf[BUF][3]), \
+                 "+v"(wf[BUF][4]), "+v"(wf[BUF][5]), "+v"(wf[BUF][6]), "+v"(wf[BUF][7]),                      \
+                 "+v"(xf[BUF][0]), "+v"(xf[BUF][1]), "+v"(xf[BUF][2]), "+v"(xf[BUF][3]),                      \
+                 "+v"(xf[BUF][4]), "+v"(xf[BUF][5]), "+v"(xf[BUF][6]), "+v"(xf[BUF][7]) : "n"(N))
+    // (inline asm with the accumulator pinned to the AGPR file: as a builtin, hipcc splits the 64 four-register accumulators
+    //  between VGPRs and AGPRs and shuffles ~200 v_accvgpr_read / write / mov through every k-step.  The hazards the compiler
+    //  no longer sees: operands come from ds_read + s_waitcnt (no wait states needed); an accumulator is touched once per 64
+    //  MFMAs; the zeroing before a tile and the reads after it are fenced with s_nop below.)
+#define GR_MFMA(I, J, BUF)                                                                                    \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(wf[BUF][I]), "v"(xf[BUF][J]))
+    // fragment read Q of k-half KH (X slab at byte offset XO, W slab at WO) into fragment buffer BUF: Q = 0..7 X, 8..15 W tiles
+#define GR_RD1(XO, WO, KH, BUF, Q)                                                                            \
+    { if ((Q) < 8) G_DSR(xf[BUF][(Q) & 7], (XO) + x_rd[KH], ((Q) & 7) * 16 * G_ROW);                          \
+      else G_DSR(wf[BUF][(Q) & 7], (WO) + w_rd[KH], ((Q) & 7) * 16 * G_ROW); }
+    // The gap behind MFMA number G (0..127) of a k-step, at most ONE memory instruction per gap:
+    //   even gaps 0..30 of each half: one fragment read each (the next half's fragments: X0..X7, W0..W7 -- all of them are
+    //                                 needed within the first MFMAs of that half, which waits for them with lgkmcnt(0))
+    //   gaps 8j+1 / 8j+5 of half 0 (j = 0..7): M0 <- destination of X piece j of stage g+2 / its DMA
+    //   gaps 8j+1 / 8j+5 of half 1 (behind the barrier): M0 <- destination of W piece j of stage g+2 / its DMA
+#define GR_GAP(G, RXO, RWO, RKH, RBUF)                                                                        \
+    {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        constexpr int g_ = (G), s_ = g_ & 63;                                                                 \
+        if constexpr ((s_ & 1) == 0 && s_ < 32) { GR_RD1(RXO, RWO, RKH, RBUF, s_ >> 1); }                     \
+        if constexpr (g_ < 64 && (s_ & 7) == 1) GD_M0(fxl + (s_ >> 3) * 4096);                                \
+        if constexpr (g_ < 64 && (s_ & 7) == 5) GD_DMAX(s_ >> 3);                                             \
+        if constexpr (g_ >= 64 && (s_ & 7) == 1) GD_M0(fwl + (s_ >> 3) * 4096);                               \
+        if constexpr (g_ >= 64 && (s_ & 7) == 5) GD_DMAW(s_ >> 3);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    // eight MFMAs of fragment row I of half SS on fragment buffer BUF, each followed by its gap
+#define GR_ROW8(SS, I, BUF, RXO, RWO, RKH, RBUF)                                                              \
+    {                                                                                                         \
+        GR_MFMA(I, 0, BUF); GR_GAP(64 * (SS) + 8 * (I) + 0, RXO, RWO, RKH, RBUF); GR_MFMA(I, 1, BUF); GR_GAP(64 * (SS) + 8 * (I) + 1, RXO, RWO, RKH, RBUF); \
+        GR_MFMA(I, 2, BUF); GR_GAP(64 * (SS) + 8 * (I) + 2, RXO, RWO, RKH, RBUF); GR_MFMA(I, 3, BUF); GR_GAP(64 * (SS) + 8 * (I) + 3, RXO, RWO, RKH, RBUF); \
+        GR_MFMA(I, 4, BUF); GR_GAP(64 * (SS) + 8 * (I) + 4, RXO, RWO, RKH, RBUF); GR_MFMA(I, 5, BUF); GR_GAP(64 * (SS) + 8 * (I) + 5, RXO, RWO, RKH, RBUF); \
+        GR_MFMA(I, 6, BUF); GR_GAP(64 * (SS) + 8 * (I) + 6, RXO, RWO, RKH, RBUF); GR_MFMA(I, 7, BUF); GR_GAP(64 * (SS) + 8 * (I) + 7, RXO, RWO, RKH, RBUF); \
+    }
+#define GR_SUB(SS, BUF, RXO, RWO, RKH, RBUF)                                                                  \
+    {                                                                                                         \
+        GR_ROW8(SS, 0, BUF, RXO, RWO, RKH, RBUF); GR_ROW8(SS, 1, BUF, RXO, RWO, RKH, RBUF);                   \
+        GR_ROW8(SS, 2, BUF, RXO, RWO, RKH, RBUF); GR_ROW8(SS, 3, BUF, RXO, RWO, RKH, RBUF);                   \
+        GR_ROW8(SS, 4, BUF, RXO, RWO, RKH, RBUF); GR_ROW8(SS, 5, BUF, RXO, RWO, RKH, RBUF);                   \
+        GR_ROW8(SS, 6, BUF, RXO, RWO, RKH, RBUF); GR_ROW8(SS, 7, BUF, RXO, RWO, RKH, RBUF);                   \
+    }
+#define GP_WRAP(V) ((V) >= G_NSLOT ? (V) - G_NSLOT : (V))
+
+    // ---- prologue: stages 0 and 1 (slabs 0..3 -> slots 0..3)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { GD_M0(lds_dma + 0 * G_SLAB + jj * 4096); asm volatile("s_nop 0"); GD_DMAX(jj); }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { GD_M0(lds_dma + 1 * G_SLAB + jj * 4096); asm volatile("s_nop 0"); GD_DMAW(jj); }
+    fetch_advance();
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { GD_M0(lds_dma + 2 * G_SLAB + jj * 4096); asm volatile("s_nop 0"); GD_DMAX(jj); }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { GD_M0(lds_dma + 3 * G_SLAB + jj * 4096); asm volatile("s_nop 0"); GD_DMAW(jj); }
+    fetch_advance();
+    G_VMCNT(16);
+    G_BARRIER();
+    {
+        const uint32_t x0_ = 0, w0_ = G_SLAB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) GR_RD1(x0_, w0_, 0, 0, q);
+    }
+
+#if GR_PROFILE
+    const bool prof = blockIdx.x == 0 && wave == 0;
+    uint64_t tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+#define GR_STAMP(K) if (prof) { const uint64_t n_ = __builtin_readcyclecounter(); tp[K] += n_ - tl; tl = n_; }
+#else
+#define GR_STAMP(K)
+#endif
+    // ---- the stage stream.  Stage g = slabs 2g (X), 2g+1 (W) in slots (2g) % 5, (2g+1) % 5; sl = (2g) % 5.
+    //        half 0 (k 0..31)   64 MFMAs + the second half's fragment reads + DMA X(g+2) -> slot (sl+4) % 5 (freed by barrier g-1)
+    //        wait               vmcnt(8): everything but X(g+2) retired -> stage g+1 landed [RAW]; lgkmcnt(0): stage g read [WAR]
+    //        barrier g          stage g+1 visible to all; slots of stage g free
+    //        half 1 (k 32..63)  64 MFMAs + the first fragment reads of stage g+1 + DMA W(g+2) -> slot sl (held X(g))
+    int sl = 0;
+    for (int c_i = 0; c_i < n_my; ++c_i) {
+        for (int c_k = 0; c_k < nk; ++c_k) {
+            const uint32_t xo = sl * G_SLAB, wo = GP_WRAP(sl + 1) * G_SLAB;
+            const uint32_t nxo = GP_WRAP(sl + 2) * G_SLAB, nwo = GP_WRAP(sl + 3) * G_SLAB;
+            const uint32_t fxl = lds_dma + GP_WRAP(sl + 4) * G_SLAB, fwl = lds_dma + sl * G_SLAB;
+            GR_LGKM(0, 0);
+            GR_STAMP(5);
+            GR_SUB(0, 0, xo, wo, 1, 1);
+            GR_STAMP(0);
+            GR_LGKM(0, 1);                                       // the second half's fragments: stage g is fully read
+            G_VMCNT(8);
+            GR_STAMP(5);
+            G_BARRIER();
+            GR_STAMP(6);
+            GR_SUB(1, 1, nxo, nwo, 0, 0);
+            fetch_advance();
+            sl = GP_WRAP(sl + 2);
+            GR_STAMP(3);
+        }
+        {
+            // ---- epilogue of tile c_i (sl already points at the next stage: the dead W slot is (sl + 4) % 5).
+            // D[n][m] of a 16 x 16 tile: a lane holds column m = lane & 15 and rows n = 4 (lane >> 4) + 0..3 -- four consecutive n.
+            // One 32-column strip (n tile i) at a time goes through the wave's 8 KiB of scratch: scratch row rho (= m within
+            // the wave tile, 64 B) lives in piece rho >> 4, its 16-byte chunk c at c ^ ((rho >> 1) & 3) (8-byte cell writes
+            // and 16-byte row reads are both bank-conflict free); global traffic moves 64-byte row segments.
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");    // the tile's last MFMAs (4 passes) -> accumulator reads
+            int64_t m0; int n0;
+            tile_origin(t_first + c_i * t_step, m0, n0);
+            unsigned char* scr = smem + GP_WRAP(sl + 4) * G_SLAB + wave * 1024;
+            const int rrow = lane >> 2, rc = lane & 3;           // row pass: 16 rows x 4 chunks per instruction
+            uint4 rnext[8];
+            if (RES) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int64_t m = m0 + wm * 128 + it * 16 + rrow;
+                    rnext[it] = make_uint4(0, 0, 0, 0);
+                    if (m < a.M) rnext[it] = *(const uint4*)(a.res + m * a.N + n0 + wn * 128 + rc * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                        // strip i = n tiles 2 i, 2 i + 1
+                const int ncol = n0 + wn * 128 + i * 32;
+                if (RES) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        *(uint4*)(scr + it * 4096 + rrow * 64 + ((rc ^ (rrow >> 1)) & 3) * 16) = rnext[it];
+                    if (i < 3) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int64_t m = m0 + wm * 128 + it * 16 + rrow;
+                            rnext[it] = make_uint4(0, 0, 0, 0);
+                            if (m < a.M) rnext[it] = *(const uint4*)(a.res + m * a.N + ncol + 32 + rc * 8);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");   // (uint4 rows and uint2 cells are distinct types: keep the passes ordered)
+                uint2 bpk[2];                                    // bias of this lane's columns n = 16 i2 + 4 lq + 0..3
+                if (BIAS) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) bpk[i2] = *(const uint2*)(a.bias + ncol + 16 * i2 + 4 * lq);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                    // m tile j: scratch rows rho = 16 j + l15 -> piece j, row-in-piece l15
+                    __builtin_amdgcn_sched_barrier(0);           // (bounds the live ranges: 8 accumulator values at a time)
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        // bytes 32 i2 + 8 lq .. + 7 of the row: chunk 2 i2 + (lq >> 1), half lq & 1
+                        unsigned char* cell = scr + j * 4096 + l15 * 64 + (((2 * i2 + (lq >> 1)) ^ (l15 >> 1)) & 3) * 16 + 8 * (lq & 1);
+                        const f32x4_t c = acc[2 * i + i2][j];
+                        float v[4] = {c[0], c[1], c[2], c[3]};
+                        if (BIAS) {
+                            v[0] += bf_lo(bpk[i2].x); v[1] += bf_hi(bpk[i2].x);
+                            v[2] += bf_lo(bpk[i2].y); v[3] += bf_hi(bpk[i2].y);
+                        }
+                        if (RES) {
+                            const uint2 r = *(const uint2*)cell;
+                            v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+                        }
+                        uint2 o;
+                        o.x = pack_bf2(v[0], v[1]);              // the one rounding
+                        o.y = pack_bf2(v[2], v[3]);
+                        *(uint2*)cell = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int64_t m = m0 + wm * 128 + it * 16 + rrow;
+                    const uint4 o = *(const uint4*)(scr + it * 4096 + rrow * 64 + ((rc ^ (rrow >> 1)) & 3) * 16);
+                    if (m < a.M) *(uint4*)(a.y + m * a.N + ncol + rc * 8) = o;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // this wave's scratch reads have returned (the stores above consumed them) before it refills the pieces
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GR_ZERO();
+            asm volatile("s_nop 7" ::: "memory");              // accumulator writes -> the next tile's first MFMAs
+            GR_STAMP(4);
+        }
+    }
+    G_VMCNT(0);                                                  // (tail re-fetches: nothing may land after the LDS is released)
+#if GR_PROFILE
+    if (prof && lane == 0) {
+        for (int k = 0; k < 7; ++k) ((float*)a.y)[k] = (float)tp[k];
+        ((float*)a.y)[7] = (float)(n_my * nk);
+        ((float*)a.y)[8] = (float)n_my;
+    }
+#endif
+}
+
 extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                                     int64_t M, int64_t N, int64_t K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || N > 0x7fffffff / 2) return -1;
@@ -305,6 +616,21 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
     a.n_tiles = (int)tiles;
     const dim3 grid((unsigned)tiles), block(512);
     hipStream_t st = (hipStream_t)stream;
+    static const int form = [] { const char* e = getenv("EVO_GEMM_FORM"); return e ? atoi(e) : 1; }();   // 1: persistent, 0: tile per workgroup
+    if (form == 1 && K >= 2 * GBK && M * K * 2 < 0xffffffffll && N * K * 2 < 0xffffffffll) {
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            n &= ~7;
+            return n < 8 ? 8 : n;
+        }();
+        const dim3 gridp((unsigned)n_cu), block4(256);
+        if (bias && residual) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true>), gridp, block4, 0, st, a);
+        else if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false>), gridp, block4, 0, st, a);
+        else if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true>), gridp, block4, 0, st, a);
+        else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false>), gridp, block4, 0, st, a);
+        return evo_launch_status();
+    }
     if (bias && residual) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, a);
     else if (bias) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, a);
     else if (residual) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, a);

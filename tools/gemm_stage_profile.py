@@ -1,0 +1,16 @@
+"""Per-segment cycles of the persistent GEMM loop (library built with -DGR_PROFILE=1: wave 0 of workgroup 0 writes its
+accumulated shader-clock deltas over the first words of y).  Usage: EVO_AMD_LIBNAME=libevo_grprof.so python tools/gemm_stage_profile.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from evo_amd.ops import default_ops
+ops = default_ops()
+for (M, N, K) in [(65544, 12288, 4096), (65544, 4096, 11008)]:
+    x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    for _ in range(3):
+        y = ops.linear_mfma(x, w, None, None)
+    torch.cuda.synchronize()
+    t = y.view(-1)[:18].view(torch.float32).tolist()
+    nst, nt = t[7], t[8]
+    names = ["half 0", "half 1 (+advance)", "-", "-", "epilogue (per tile)", "lgkmcnt waits", "barrier"]
+    print(f"M={M} N={N} K={K}: stages={int(nst)} tiles={int(nt)} | " + ", ".join(
+        f"{n}={t[i] / (nt if i == 4 else nst):.0f}" for i, n in enumerate(names)) + f" | per k-step total {(sum(t[:4]) + t[5] + t[6]) / nst:.0f}")
