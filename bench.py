@@ -252,7 +252,8 @@ def main():
     kernels = {k: {"launches_per_step": v[0] // args.steps, "avg_ms": v[1]} for k, v in ksum.items()}
     kernels["attn_fwd"]["tflops"] = attn_flops / (ksum["attn_fwd"][1] * 1e-3) / 1e12
     kernels["attn_fwd"]["mfma_frac"] = kernels["attn_fwd"]["tflops"] / MFMA_BF16_PEAK_TFLOPS
-    gemm_ms = ksum["gemm"][1] * ksum["gemm"][0] / args.steps
+    # dense layers: "gemm_mfma" = the hand-written kernel (csrc/gemm.hip), "gemm" = hipBLASLt (only with EVO_AMD_GEMM=hipblaslt)
+    gemm_ms = sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm", "gemm_mfma") if k in ksum)
     out = {
         "metric": "nucleotides/sec forward scoring, evo-1 7B", "value": value, "unit": "nt/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -265,7 +266,20 @@ def main():
                    "parallelism": "independent batches per GPU" if n_gpus > 1 else "single GPU"},
         "model_tflops": flops_per_token(T) * B * T / (dt / args.steps) / 1e12,
         "roofline": roofline, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
+        "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
     }
+    # ------------------------------------------------------------------ the same step with EVERY dense layer hand-written
+    if n_gpus == 1 and not ops.all_gemm_mfma:
+        try:
+            ops.all_gemm_mfma = True
+            dt2 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+            out["all_hand_written_gemm"] = {"value": B * nt / (dt2 / 3), "unit": "nt/s", "ms_per_step": dt2 / 3 * 1e3, "steps": 3,
+                                            "note": "csrc/gemm.hip persistent kernel for all 128 dense layers (EVO_AMD_GEMM=mfma); "
+                                                    "the headline keeps hipBLASLt for the plain Hyena / MLP GEMMs"}
+        except Exception as e:  # noqa: BLE001
+            out["all_hand_written_gemm"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.all_gemm_mfma = False
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         try:

@@ -307,6 +307,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_kernel(GemmArgs a) {
 // Epilogue scratch: after the barrier of a tile's last k-step the slot of its last W slab is dead until this very wave
 // refills it in the next k-step -- each wave transposes through exactly the eight 1-KiB pieces it will DMA into (one
 // 32-column strip of its tile at a time, rows of 64 B, XOR-swizzled), so no barrier is needed.
+#ifndef GR_DGAP
+#define GR_DGAP 8                            // gaps between the DMA pieces of a half step (8 pieces: 8 = spread over all 64 gaps, 4 = first 32)
+#endif
 #ifndef GR_PROFILE
 #define GR_PROFILE 0                         // 1: wave 0 of workgroup 0 accumulates cycles per loop segment, written over y (tools/gemm_stage_profile.py)
 #endif
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
         fxs = (uint32_t)(m0 * kb);
         fws = (uint32_t)n0 * kb;
     }
-    auto fetch_advance = [&]() {                                 // past the last stage: stay (harmless re-fetches keep the counts constant)
+    auto fetch_advance = [&]() {                                 // (prologue only; past the last stage: stay)
         if (f_k + 1 < nk) { ++f_k; fxs += GBK * 2; fws += GBK * 2; }
         else if (f_i + 1 < n_my) {
             ++f_i; f_k = 0;
@@ -380,7 +383,30 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
             fws = (uint32_t)n0 * kb;
         }
     };
+    // Inside the stream the cursor moves WITHOUT branches (a taken branch in the middle of the MFMA stream is an instruction
+    // refetch with the pipe idle; the first version of this loop had two per k-step): the soffsets of the first stage of the
+    // tile after the fetch tile (nx0, nw0) are kept ready -- recomputed once per tile, in the epilogue -- and the step is
+    // a chain of scalar selects.  Past the last stage the cursor stays (harmless re-fetches keep the vmcnt counts constant).
+    uint32_t nx0 = 0, nw0 = 0, nfxs = 0, nfws = 0;
+    auto next_tile_origin = [&]() {
+        if (f_i + 1 < n_my) {
+            int64_t m0; int n0;
+            tile_origin(t_first + (f_i + 1) * t_step, m0, n0);
+            nx0 = (uint32_t)(m0 * kb);
+            nw0 = (uint32_t)n0 * kb;
+        }
+    };
+    auto fetch_next = [&]() {
+        const bool more_k = f_k + 1 < nk, more_t = f_i + 1 < n_my;
+        nfxs = more_k ? fxs + GBK * 2 : (more_t ? nx0 : fxs);
+        nfws = more_k ? fws + GBK * 2 : (more_t ? nw0 : fws);
+        f_i = (!more_k && more_t) ? f_i + 1 : f_i;
+        f_k = more_k ? f_k + 1 : (more_t ? 0 : f_k);
+    };
 #define GD_M0(V) asm volatile("s_mov_b32 m0, %0" ::"s"(V) : "memory", "m0")
+#ifndef GR_ABL
+#define GR_ABL 0                             // ablation bits (measurement builds only): 1 no in-loop DMA, 2 no in-loop barrier, 8 no in-loop fragment reads, 16 no M0 writes
+#endif
 #define GD_DMAX(JJ) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[JJ]), "s"(rx), "s"(fxs) : "memory")
 #define GD_DMAW(JJ) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[JJ]), "s"(rw), "s"(fws) : "memory")
 
@@ -421,18 +447,28 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
       else G_DSR(wf[BUF][(Q) & 7], (WO) + w_rd[KH], ((Q) & 7) * 16 * G_ROW); }
     // The gap behind MFMA number G (0..127) of a k-step, at most ONE memory instruction per gap:
     //   even gaps 0..30 of each half: one fragment read each (the next half's fragments: X0..X7, W0..W7 -- all of them are
-    //                                 needed within the first MFMAs of that half, which waits for them with lgkmcnt(0))
+    //                                 needed within the first MFMAs of that half, which waits for them with lgkmcnt(0); spreading
+    //                                 half 1's reads over all 64 gaps with row-wise counted waits measured neutral)
     //   gaps 8j+1 / 8j+5 of half 0 (j = 0..7): M0 <- destination of X piece j of stage g+2 / its DMA
     //   gaps 8j+1 / 8j+5 of half 1 (behind the barrier): M0 <- destination of W piece j of stage g+2 / its DMA
 #define GR_GAP(G, RXO, RWO, RKH, RBUF)                                                                        \
     {                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         constexpr int g_ = (G), s_ = g_ & 63;                                                                 \
-        if constexpr ((s_ & 1) == 0 && s_ < 32) { GR_RD1(RXO, RWO, RKH, RBUF, s_ >> 1); }                     \
-        if constexpr (g_ < 64 && (s_ & 7) == 1) GD_M0(fxl + (s_ >> 3) * 4096);                                \
-        if constexpr (g_ < 64 && (s_ & 7) == 5) GD_DMAX(s_ >> 3);                                             \
-        if constexpr (g_ >= 64 && (s_ & 7) == 1) GD_M0(fwl + (s_ >> 3) * 4096);                               \
-        if constexpr (g_ >= 64 && (s_ & 7) == 5) GD_DMAW(s_ >> 3);                                            \
+        if constexpr ((s_ & 1) == 0 && s_ < 32 && !(GR_ABL & 8)) { GR_RD1(RXO, RWO, RKH, RBUF, s_ >> 1); }    \
+        if constexpr (g_ < 64 && s_ < 8 * GR_DGAP && (s_ % GR_DGAP) == 1 && !(GR_ABL & 16)) GD_M0(fxl + (s_ / GR_DGAP) * 4096);        \
+        if constexpr (g_ < 64 && s_ < 8 * GR_DGAP && (s_ % GR_DGAP) == GR_DGAP / 2 + 1 && !(GR_ABL & 1)) GD_DMAX(s_ / GR_DGAP);       \
+        if constexpr (g_ >= 64 && s_ < 8 * GR_DGAP && (s_ % GR_DGAP) == 1 && !(GR_ABL & 16)) GD_M0(fwl + (s_ / GR_DGAP) * 4096);       \
+        if constexpr (g_ >= 64 && s_ < 8 * GR_DGAP && (s_ % GR_DGAP) == GR_DGAP / 2 + 1 && !(GR_ABL & 1)) GD_DMAW(s_ / GR_DGAP);      \
+        /* scalar bookkeeping of the NEXT k-step rides in otherwise empty gaps (at the loop top it cost ~100 cycles of idle */ \
+        /* MFMA pipe per k-step): gap 66 next soffsets (this k-step's X pieces are out), gap 98 next ring offsets, gap 126 W soffset */ \
+        if constexpr (g_ == 66) { fetch_next(); fxs = nfxs; }                                                 \
+        if constexpr (g_ == 98) {                                                                             \
+            const int s2_ = GP_WRAP(sl + 2);                                                                  \
+            t_xo = s2_ * G_SLAB; t_wo = GP_WRAP(s2_ + 1) * G_SLAB; t_nxo = GP_WRAP(s2_ + 2) * G_SLAB;         \
+            t_nwo = GP_WRAP(s2_ + 3) * G_SLAB; t_fxl = lds_dma + GP_WRAP(s2_ + 4) * G_SLAB; t_fwl = lds_dma + s2_ * G_SLAB; t_sl = s2_; \
+        }                                                                                                     \
+        if constexpr (g_ == 126) { fws = nfws; }                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
     // eight MFMAs of fragment row I of half SS on fragment buffer BUF, each followed by its gap
@@ -463,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) { GD_M0(lds_dma + 3 * G_SLAB + jj * 4096); asm volatile("s_nop 0"); GD_DMAW(jj); }
     fetch_advance();
+    next_tile_origin();
     G_VMCNT(16);
     G_BARRIER();
     {
@@ -483,24 +520,23 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     //        wait               vmcnt(8): everything but X(g+2) retired -> stage g+1 landed [RAW]; lgkmcnt(0): stage g read [WAR]
     //        barrier g          stage g+1 visible to all; slots of stage g free
     //        half 1 (k 32..63)  64 MFMAs + the first fragment reads of stage g+1 + DMA W(g+2) -> slot sl (held X(g))
-    int sl = 0;
+    int sl = 0, t_sl = 0;
+    uint32_t xo = 0, wo = G_SLAB, nxo = 2 * G_SLAB, nwo = 3 * G_SLAB, fxl = lds_dma + 4 * G_SLAB, fwl = lds_dma;
+    uint32_t t_xo = 0, t_wo = 0, t_nxo = 0, t_nwo = 0, t_fxl = 0, t_fwl = 0;
     for (int c_i = 0; c_i < n_my; ++c_i) {
         for (int c_k = 0; c_k < nk; ++c_k) {
-            const uint32_t xo = sl * G_SLAB, wo = GP_WRAP(sl + 1) * G_SLAB;
-            const uint32_t nxo = GP_WRAP(sl + 2) * G_SLAB, nwo = GP_WRAP(sl + 3) * G_SLAB;
-            const uint32_t fxl = lds_dma + GP_WRAP(sl + 4) * G_SLAB, fwl = lds_dma + sl * G_SLAB;
             GR_LGKM(0, 0);
             GR_STAMP(5);
             GR_SUB(0, 0, xo, wo, 1, 1);
             GR_STAMP(0);
             GR_LGKM(0, 1);                                       // the second half's fragments: stage g is fully read
+            GR_STAMP(1);
             G_VMCNT(8);
-            GR_STAMP(5);
-            G_BARRIER();
+            GR_STAMP(2);
+            if (!(GR_ABL & 2)) G_BARRIER();
             GR_STAMP(6);
             GR_SUB(1, 1, nxo, nwo, 0, 0);
-            fetch_advance();
-            sl = GP_WRAP(sl + 2);
+            xo = t_xo; wo = t_wo; nxo = t_nxo; nwo = t_nwo; fxl = t_fxl; fwl = t_fwl; sl = t_sl;
             GR_STAMP(3);
         }
         {
@@ -581,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
             }
             // this wave's scratch reads have returned (the stores above consumed them) before it refills the pieces
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            next_tile_origin();                                  // (the fetch cursor entered tile c_i + 1 two stages ago)
             GR_ZERO();
             asm volatile("s_nop 7" ::: "memory");              // accumulator writes -> the next tile's first MFMAs
             GR_STAMP(4);

@@ -158,6 +158,10 @@ class HipOps:
             raise EvoLibraryError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.seg_len_override = int(os.environ.get("EVO_AMD_SEG_LEN", "0"))
         self.attn_gemm_mfma = os.environ.get("EVO_AMD_ATTN_GEMM", "mfma").lower() != "hipblaslt"
+        # EVO_AMD_GEMM=mfma puts EVERY prefill dense layer on the hand-written persistent kernel (csrc/gemm.hip: 92-95 % of
+        # hipBLASLt per layer, 96 % end to end -- profiles/r02_gemm_notes.txt); the default keeps the plain Hyena / MLP GEMMs on
+        # the library and the attention block's fused-epilogue projections on the hand-written kernel
+        self.all_gemm_mfma = os.environ.get("EVO_AMD_GEMM", "hipblaslt").lower() == "mfma"
         self.timer: Optional[KernelTimer] = None
         self.validate_ids = os.environ.get("EVO_AMD_VALIDATE_IDS", "1") != "0"   # one 4-byte D2H read per forward
         self.hyena_mfma = os.environ.get("EVO_AMD_HYENA", "mfma").lower() != "modal"   # single-pass matrix-core operator
@@ -203,15 +207,18 @@ class HipOps:
             self._linear_into(y[: M - r], x[: M - r], w, b, mfma)
             self._linear_small_m(x[M - r:], w, b, None, out=y[M - r:])
             return y
-        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w):
+        if self._take_mfma(mfma) and self.mfma_linear_ok(x, w):
             return self.linear_mfma(x, w, b)
         with self._t("gemm"):
             if b is not None:
                 return torch.addmm(b, x, w.t())
             return torch.mm(x, w.t())
 
+    def _take_mfma(self, mfma: bool) -> bool:
+        return self.all_gemm_mfma or (mfma and self.attn_gemm_mfma)
+
     def _linear_into(self, y, x, w, b, mfma):
-        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w):
+        if self._take_mfma(mfma) and self.mfma_linear_ok(x, w):
             with self._t("gemm_mfma"):
                 _check(self.lib.evo_linear_mfma_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), None, y.data_ptr(),
                                                      x.shape[0], w.shape[0], x.shape[1], _stream()), "evo_linear_mfma_bf16")
@@ -237,7 +244,7 @@ class HipOps:
             self.linear_residual_(res[: M - r], x[: M - r], w, mfma)
             self._linear_small_m(x[M - r:], w, None, res[M - r:])
             return res
-        if mfma and self.attn_gemm_mfma and self.mfma_linear_ok(x, w) and res.is_contiguous():
+        if self._take_mfma(mfma) and self.mfma_linear_ok(x, w) and res.is_contiguous():
             return self.linear_mfma(x, w, None, res)
         with self._t("gemm"):
             return res.addmm_(x, w.t())
