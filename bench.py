@@ -272,7 +272,8 @@ def main():
     if n_gpus == 1 and not ops.all_gemm_mfma:
         try:
             ops.all_gemm_mfma = True
-            dt2 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+            with torch.inference_mode():
+                dt2 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
             out["all_hand_written_gemm"] = {"value": B * nt / (dt2 / 3), "unit": "nt/s", "ms_per_step": dt2 / 3 * 1e3, "steps": 3,
                                             "note": "csrc/gemm.hip persistent kernel for all 128 dense layers (EVO_AMD_GEMM=mfma); "
                                                     "the headline keeps hipBLASLt for the plain Hyena / MLP GEMMs"}

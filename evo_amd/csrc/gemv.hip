@@ -123,6 +123,7 @@ template <int M, int R>
 __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
                                                         const uint4* __restrict__ w, const uint16_t* __restrict__ bias,
                                                         uint16_t* __restrict__ y, int N, int nvec, float eps, float inv_sqrt_d) {
+    constexpr int GV_R = R;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * R;
@@ -132,6 +133,15 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     for (int r = 0; r < R; ++r) {
         int64_t n = n0 + r < N ? n0 + r : N - 1;
         wrow[r] = w + n * nvec;
+    }
+    // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
+    // once instead of after a ~1.5 us reduction, and every later trip's loads are issued ahead of the trip that consumes
+    // the previous ones (same arithmetic in the same order: results are bit-identical to the single-buffered loop)
+    uint4 wa[2 * GV_R];
+    const bool gv_any = lane + 64 < nvec;
+    if (gv_any) {
+#pragma unroll
+        for (int r = 0; r < GV_R; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[GV_R + r] = ld_stream(wrow[r] + lane + 64); }
     }
     float inv[M];
 #pragma unroll
@@ -162,14 +172,21 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     int v = lane;
     for (; v + 64 < nvec; v += 128) {
-        uint4 w0[R], w1[R];
+        uint4 wb[2 * GV_R];
+        const bool more = v + 128 + 64 < nvec;
+        if (more) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+            for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+        }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
         }
     }
     for (; v < nvec; v += 64) {
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     const uint16_t* __restrict__ fir_w, const uint16_t* __restrict__ fir_b, const float* __restrict__ poles,
     const float* __restrict__ residues, const uint16_t* __restrict__ dskip, uint16_t* __restrict__ y, int D, int nvec,
     float eps, float inv_sqrt_d) {
-    constexpr int HDc = 128, NSc = 8;
+    constexpr int HDc = 128, NSc = 8, GV_R = 6;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = blockIdx.x * 4 + wave;                     // channel pair index over D / 2
@@ -221,6 +238,15 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     const uint4* wrow[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r >> 1) * HDc + j0 + (r & 1)) * nvec;
+    // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
+    // once instead of after a ~1.5 us reduction, and every later trip's loads are issued ahead of the trip that consumes
+    // the previous ones (same arithmetic in the same order: results are bit-identical to the single-buffered loop)
+    uint4 wa[2 * GV_R];
+    const bool gv_any = lane + 64 < nvec;
+    if (gv_any) {
+#pragma unroll
+        for (int r = 0; r < GV_R; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[GV_R + r] = ld_stream(wrow[r] + lane + 64); }
+    }
     float inv[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -250,14 +276,21 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     int v = lane;
     for (; v + 64 < nvec; v += 128) {
-        uint4 w0[6], w1[6];
+        uint4 wb[2 * GV_R];
+        const bool more = v + 128 + 64 < nvec;
+        if (more) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+            for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+        }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
         }
     }
     for (; v < nvec; v += 64) {
