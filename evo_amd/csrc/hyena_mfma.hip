@@ -5,11 +5,11 @@
 // reads the x1|v thirds of z twice.  This kernel evaluates the same operator -- FIR(k=3) + bias, x1*v, long convolution
 // with h_k = Re sum_s R_s p_s^k, (y + x1v*D)*x2 -- in ONE pass with the heavy arithmetic on MFMA:
 //
-//   workgroup = (batch row b, 16 channels), 8 waves, walks the sequence tile by tile (512 steps = 16 blocks of 32),
-//   carrying the 16 real modal states of its channels in registers -- sequential in time, parallel over channels, so
-//   there is no segment pass and no carry workspace: z is read once, y written once (32,768 B/token/layer).
+//   workgroup = (batch rows b0, b0 + nb_split, ..., 16 channels), 8 waves, walks the sequence tile by tile (512 steps = 16
+//   blocks of 32), carrying the 16 real modal states of its channels in registers -- sequential in time, parallel over
+//   channels, so there is no segment pass and no carry workspace: z is read once, y written once (32,768 B/token/layer).
 //   Per tile and channel (constants from evo_amd/hyena_tables.py, math pinned on the CPU by tests/test_hyena_blocked.py):
-//     y0 = T0 . X          block Toeplitz (32 x 32 lower triangular) x 16 blocks     6 x v_mfma_f32_16x16x32_bf16
+//     y0 = T0 . X          block Toeplitz (32 x 32 lower triangular, filter.D on the diagonal) x 16 blocks   6 x v_mfma_f32_16x16x32_bf16
 //     E  = W  . X          block aggregates: 16 state components x 16 blocks         5 x v_mfma_f32_16x16x32_bf16
 //     S  = scan(E)         Kogge-Stone over the 16 blocks with p^32, p^64, p^128, p^256 (DPP row shifts, fp32 VALU)
 //     y  = y0 + G . S      contribution of the state entering each block              4 x v_mfma_f32_16x16x32_bf16 (G, S split hi + lo)
@@ -18,15 +18,27 @@
 //
 // z layout: GROUPED -- the projection's output columns are ordered [group][x2 16 | x1 16 | v 16] (hyena_tables.
 // group_permutation applied to the rows of the projection weight at load time), so that the 96 bytes a workgroup needs of
-// a row are contiguous.  With the reference's column order (x2 | x1 | v blocks of 128 per head) they are three 32-byte
-// pieces in three cache lines, and the kernel was bound by the L1's tag rate: a 1-KiB LDS-DMA instruction that touches 32
-// lines costs ~170 cycles (measured: 2 TB/s with NO arithmetic at identical HBM traffic; TCC requests 3x those of
-// hyena_apply -- profiles/r02_hyena_mfma_notes.txt).
-// Data path: the tile's rows arrive by global->LDS DMA, one tile ahead, into two alternating buffers, every wait a counted
-// vmcnt (the VM counter retires in order: DMA pieces and y stores are counted together); stage 1 (all 512 threads, lanes over channel pairs x time) computes FIR and x1*v and writes
-// the bf16 planes TRANSPOSED ([channel][time], what the MFMA B operand wants); stage 2 (wave = 2 channels) runs the
-// MFMAs and the scan and leaves (y + x1v D)^T (fp32) in place of its channels' planes; stage 3 (all threads) runs the x2 FIR,
-// applies the x2 gate and stores y.  The four workgroups that share a 128-byte line of z (and of y) are numbered onto one XCD.
+// a row are contiguous (with the reference's column order the kernel was bound by the L1's tag rate at 2 TB/s with no
+// arithmetic at all: profiles/r02_hyena_mfma_notes.txt).
+//
+// Three stages per tile, SOFTWARE-PIPELINED over three consecutive tiles, ONE barrier per tile:
+//   S1(t)  all threads (channel pair x 8 steps): FIR of x1 and v, x = x1*v, bf16 hi | lo "planes" [channel][time]; x2 rows parked
+//   S2(t)  wave = 2 channels: the MFMAs and the scan; leaves (y + x1v D)^T (fp32) in place of its channels' planes
+//   S3(t)  all threads: FIR of x2, gate, 16-byte y stores
+// In the interval between two barriers a wave runs S3(k-1), S1(k+1) and S2(k) -- waves 0-3 in this order, waves 4-7 with S2
+// first, so that on every SIMD one wave is in the MFMA stage while the other runs the VALU stages.  What makes one
+// barrier enough:
+//   * the z rows a wave consumes are exactly the rows it fetched (64 steps + 2 rows of FIR history, global->LDS DMA): its
+//     window is wave-private (single buffer, consumed by S1 and refilled right behind it) -- no barrier, only this wave's
+//     counted vmcnt.  S1 also copies the window's x2 dwords into a two-tile ring of the same wave for S3 two intervals
+//     later -- fetching x2 a second time when S3 needs it cost +21 % / +63 % L2-miss read traffic at 8 x 8,193 / 131 k
+//     (the lines had left the XCD's 4 MiB L2 by then);
+//   * the planes are double-buffered, and a thread's plane unit (8 steps: 16 B hi | 16 B lo) is byte for byte the unit of
+//     y^T (8 fp32) it reads in S3: S3(k-1) and S1(k+1) touch the same bytes of the same buffer from the same thread, in
+//     program order; S2(k) works on the other buffer, on the wave's own two channels.
+//   The barrier at the end of interval k publishes planes(k+1) to S2(k+1) and y^T(k) to S3(k).
+// The first version ran the three stages strictly one after the other behind three barriers: 9.5-11.4 k cycles per tile, of
+// which 2.3-3.3 k barrier skew, against an HBM floor of 6.3 k.
 // Entry point and reference citation: include/evo_mi355x.h.
 #include "common.h"
 #include "../../include/evo_mi355x.h"
@@ -35,25 +47,28 @@
 #define HM_L 32                             // steps per block
 #define HM_NB 16                            // blocks per tile
 #define HM_TT (HM_L * HM_NB)                // 512 steps per tile
-#define HM_ROWS (HM_TT + 2)                 // + 2 rows of FIR history
-#define HM_ROWB (3 * HM_CH * 2)             // 96 B per row: x2 | x1 | v of the group, CONTIGUOUS in the grouped z layout
-// LDS layouts are chosen against bank conflicts (the first version spent 80 % of its LDS cycles in conflicts,
-// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, and was LDS-bound):
-//  * z image: row r sits in slot r + r/8 (a gap slot after every 8 rows): the threads of stages 1 / 3 own 8 consecutive rows
-//    each, so neighbouring time phases are 9 slots = 216 dwords = 24 (mod 32) banks apart instead of 0;
-//  * planes: the 16-byte chunk m (8 steps) of a channel sits at m ^ ((m >> 4) & 3); y^T: chunk k (4 steps) at k ^ ((k >> 3) & 7);
-//    the per-channel pitch is an odd number of 16-byte units.
-#define HM_SLOTS (HM_ROWS + HM_ROWS / 8)    // 578 slots of 96 B
-#define HM_NDMA 55                          // ceil(578 * 96 / 1024) one-KiB DMA pieces per tile
-#define HM_ZBUF (HM_NDMA * 1024)            // 56,320 B
-#define HM_PLANE (HM_TT * 2 + 16)           // 1,040 B: one bf16 plane of one channel (+ pad; keeps 16-byte alignment)
-#define HM_XTCH (2 * HM_PLANE + 16)         // 2,096 B per channel (16 x 131): hi | lo planes, later y^T fp32 [512]
-#define HM_FIRB (8 * 3 * 4 * 8 + HM_CH * 4)  // FIR taps + bias of the 8 channel pairs as f32x2 (768 B) + D of the 16 channels
-#define HM_PWB (HM_CH * 4 * 16 * 4)          // p^32, p^64, p^128, p^256 of the 16 channels: [ch][k][16 components] f32, 4 KiB
-#define HM_LDS (2 * HM_ZBUF + HM_CH * HM_XTCH + HM_FIRB + HM_PWB)   // 151,104 B: [z0][z1][planes][fir][D][powers]
-#define HM_SLOT(R) ((R) + ((R) >> 3))       // LDS slot of buffer row R
-#define HM_PCH(M) ((M) ^ (((M) >> 4) & 3))  // stored position of plane chunk M (16 B = 8 steps)
-#define HM_YCH(K) ((K) ^ (((K) >> 3) & 7))  // stored position of y^T chunk K (16 B = 4 steps)
+#define HM_ROWB (3 * HM_CH * 2)             // 96 B of a z row per workgroup: x2 | x1 | v of the group, CONTIGUOUS (grouped z layout)
+#define HM_WROWS 66                         // rows of a wave's window: its 64 steps + 2 rows of FIR history
+// LDS layouts against bank conflicts: a thread of S1 owns 8 consecutive rows, so neighbouring time phases would sit a
+// multiple of 128 B apart; a 32-byte gap after every 8 rows (800 B = 200 dwords = 8 mod 32) puts the eight phases of a wave
+// on 4 x 2 distinct bank groups.
+#define HM_WIN_GROUP (8 * HM_ROWB + 32)     // window: 8 rows of 96 B + gap
+#define HM_WIN_WAVE 7168                    // 7 one-KiB DMA pieces (8 groups + 2 rows = 6592 B)
+#define HM_WIN_ROW(R) (((R) >> 3) * HM_WIN_GROUP + ((R) & 7) * HM_ROWB)
+// parked x2 rows (66 rows of 32 B per wave and tile, later the staged outputs): row r = 8 phase + i sits in slot 8 i + phase
+// (rows 64, 65 in slots 64, 65), so that the eight phases of a wave read / write 256 contiguous bytes per access
+#define HM_X2P_TILE (HM_WROWS * 32)         // 2,112 B
+#define HM_X2P_SLOT(R) ((R) < 64 ? (((R) & 7) * 8 + ((R) >> 3)) : (R))
+#define HM_UNIT 32                          // plane unit: 8 steps = [16 B hi | 16 B lo]; later 8 fp32 of (y + x1v D)
+#define HM_XTCH (64 * HM_UNIT + 16)         // 2,064 B per channel (odd multiple of 16)
+#define HM_OFF_WIN 0
+#define HM_OFF_X2P (8 * HM_WIN_WAVE)                        // 57,344
+#define HM_OFF_P (HM_OFF_X2P + 8 * 2 * HM_X2P_TILE)         // 91,136
+#define HM_OFF_FIR (HM_OFF_P + 2 * HM_CH * HM_XTCH)         // 157,184
+#define HM_FIRB (8 * 3 * 4 * 8 + 64)                        // FIR taps + bias of the 8 channel pairs as f32x2 (768 B) + pad
+#define HM_OFF_PW (HM_OFF_FIR + HM_FIRB)                    // 158,016
+#define HM_PWB (HM_CH * 4 * 16 * 4)                         // p^32, p^64, p^128, p^256 of the 16 channels: [ch][k][16 components] f32, 4 KiB
+#define HM_LDS (HM_OFF_PW + HM_PWB)                         // 162,112 B
 #define HM_TABW 52
 #ifndef HM_PROFILE
 #define HM_PROFILE 0
@@ -95,10 +110,9 @@ __global__ __launch_bounds__(512, 1) void hyena_mfma_kernel(HmArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- which (batch row, 16-channel group): block i runs on XCD i % 8; the four groups that share a 128-byte line of
-    //      z / y are the four consecutive slots of one XCD
-    //      A workgroup keeps its channel group and walks batch rows b0, b0 + nb_split, ...: the 13 KiB of MFMA constants
-    //      per channel are loaded once per workgroup.
+    // ---- which (batch rows, 16-channel group): block i runs on XCD i % 8; the four groups that share a 128-byte line of
+    //      z / y are the four consecutive slots of one XCD.  A workgroup keeps its channel group and walks batch rows b0,
+    //      b0 + nb_split, ...: the 13 KiB of MFMA constants per channel are loaded once per workgroup.
     int b0, cg;
     {
         const int bid = blockIdx.x, total = gridDim.x;
@@ -111,55 +125,63 @@ __global__ __launch_bounds__(512, 1) void hyena_mfma_kernel(HmArgs a) {
     const int h = cg >> 3, cw0 = (cg & 7) * HM_CH;          // head, first channel within the head
     const int d0 = h * 128 + cw0;                           // first output channel
     const int64_t rowbytes = (int64_t)a.D * 6;
-    unsigned char* xt = smem + 2 * HM_ZBUF;
+    unsigned char* win = smem + HM_OFF_WIN + wave * HM_WIN_WAVE;          // this wave's window of z rows
+    unsigned char* x2pw = smem + HM_OFF_X2P + wave * (2 * HM_X2P_TILE);   // this wave's parked-x2 ring (two tiles)
+    unsigned char* pl = smem + HM_OFF_P;                                  // planes / y^T: [2][16 channels][HM_XTCH]
 
-    // ---- DMA plan: piece i (wave, wave + 8, ...) = 1 KiB of the tile buffer; chunk c = 64 i + lane is 16 bytes of row c / 6
-    //      (slot 9 m + 8 is a gap: those lanes re-fetch the neighbouring row into it)
-    //      Interior tiles (every row of the buffer inside the sequence) address with one precomputed per-lane byte offset per
-    //      piece; the first / last tile of a row clamp row by row.
-    int dma_off[7], dma_row[7];
+    // ---- DMA plan: the wave's window = rows (tile start + 64 wave - 2) + 0..65.  Chunk c = 64 i + lane of piece i is 16
+    //      bytes of the LDS image (lane-linear); gap and tail chunks re-fetch a valid chunk (never read back).
+    int w_off[7], w_row[7];
 #pragma unroll
-    for (int jj = 0; jj < 7; ++jj) {
-        int c = (wave + 8 * jj) * 64 + lane;
-        if (c > HM_SLOTS * 6 - 1) c = HM_SLOTS * 6 - 1;     // tail of the last piece: re-fetch the last chunk (pad space)
-        const int slot = c / 6;
-        int row = slot - slot / 9;                          // slots 9m .. 9m+7 hold rows 8m .. 8m+7; 9m+8 is the gap
-        if (row > HM_ROWS - 1) row = HM_ROWS - 1;
-        dma_row[jj] = row;
-        dma_off[jj] = row * (int)rowbytes + cg * HM_ROWB + (c - 6 * slot) * 16;      // < 2^31: 514 rows of <= 3 MiB
+    for (int i = 0; i < 7; ++i) {
+        const int c = 64 * i + lane;
+        const int g8 = c / 50, rem = c - 50 * g8;           // 50 chunks per group: 48 of data + 2 of gap
+        int row = 8 * g8 + (rem < 48 ? rem / 6 : 7);
+        const int col = rem < 48 ? (rem % 6) * 16 : 80;
+        if (row > HM_WROWS - 1) row = HM_WROWS - 1;
+        w_row[i] = row;
+        w_off[i] = row * (int)rowbytes + cg * HM_ROWB + col;                // < 2^31: 66 rows of <= 3 MiB
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int n_rows = (a.B - b0 + a.nb_split - 1) / a.nb_split;
     const int n_steps = n_rows * a.n_tiles;                 // global step = (batch row of this workgroup, tile)
-    auto dma_tile = [&](int step) {                         // rows of `step` -> buffer step & 1
-        const unsigned char* zb = a.z + (int64_t)(b0 + (step / a.n_tiles) * a.nb_split) * a.T * rowbytes;
-        const int64_t t_first = (int64_t)(step % a.n_tiles) * HM_TT - 2;
-        const bool interior = t_first >= 0 && t_first + HM_ROWS <= a.T;
+    struct StepInfo { int b; int tile; int64_t t0; };
+    auto step_info = [&](int step) {
+        StepInfo s;
+        const int ri = step / a.n_tiles;
+        s.tile = step - ri * a.n_tiles;
+        s.b = b0 + ri * a.nb_split;
+        s.t0 = (int64_t)s.tile * HM_TT;
+        return s;
+    };
+#define HM_DMA(LDSADDR, SRC)                                                                                  \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(LDSADDR), "v"(SRC) : "memory", "m0")
+    auto dma_win = [&](int step) {                          // z rows of `step` -> the wave's window (7 pieces)
+        const StepInfo s = step_info(step);
+        const unsigned char* zb = a.z + (int64_t)s.b * a.T * rowbytes;
+        const int64_t t_first = s.t0 + 64 * wave - 2;
+        const bool interior = t_first >= 0 && t_first + HM_WROWS <= a.T;
         const unsigned char* base = zb + t_first * rowbytes;
 #pragma unroll
-        for (int jj = 0; jj < 7; ++jj) {
-            const int i = wave + 8 * jj;
-            if (i < HM_NDMA) {
-                const unsigned char* src;
-                if (interior) {
-                    src = base + dma_off[jj];
-                } else {
-                    int64_t t = t_first + dma_row[jj];
-                    t = t < 0 ? (int64_t)0 : (t > a.T - 1 ? a.T - 1 : t);
-                    src = zb + t * rowbytes + (dma_off[jj] - dma_row[jj] * (int)rowbytes);
-                }
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             ::"s"(lds0 + (step & 1) * HM_ZBUF + i * 1024), "v"(src) : "memory", "m0");
+        for (int i = 0; i < 7; ++i) {
+            const unsigned char* src;
+            if (interior) src = base + w_off[i];
+            else {
+                int64_t t = t_first + w_row[i];
+                t = t < 0 ? (int64_t)0 : (t > a.T - 1 ? a.T - 1 : t);
+                src = zb + t * rowbytes + (w_off[i] - w_row[i] * (int)rowbytes);
             }
+            HM_DMA(lds0 + HM_OFF_WIN + wave * HM_WIN_WAVE + i * 1024, src);
         }
     };
 
-    // ---- stage 1 / 3 thread mapping: channel pair p (channels 2p, 2p+1 of the group) x 64 time phases of 8 steps
-    const int p = tid & 7, ph = tid >> 3;
+    // ---- stage 1 / 3 thread mapping: channel pair p (channels 2p, 2p+1 of the group) x time phase ph (8 steps); the wave's
+    //      eight phases phl = 0..7 are its 64 steps
+    const int p = tid & 7, ph = tid >> 3, phl = ph & 7;
     // FIR taps / bias live in LDS ([pair][group][tap 0..2, bias] as f32x2) and are read at the head of stages 1 and 3: held in
     // registers they pushed stage 2 over the 256-VGPR budget, and a scratch reload inside the tile loop is a VMEM load whose
     // compiler-placed vmcnt(0) would drain the DMA in flight.
-    f32x2_t* firl = (f32x2_t*)(smem + 2 * HM_ZBUF + HM_CH * HM_XTCH);
+    f32x2_t* firl = (f32x2_t*)(smem + HM_OFF_FIR);
     if (tid < 8 * 3 * 4) {
         const int pp = tid / 12, rem = tid - 12 * pp, g = rem >> 2, k = rem & 3;
         const int c = h * 384 + g * 128 + cw0 + 2 * pp;
@@ -179,164 +201,152 @@ __global__ __launch_bounds__(512, 1) void hyena_mfma_kernel(HmArgs a) {
 #pragma unroll
         for (int w = 0; w < 36; ++w) tb[cc][w] = tp[w * 64];
     }
-    float* pwl = (float*)(firl + 96) + HM_CH;                                // [ch][k][16] f32
+    float* pwl = (float*)(smem + HM_OFF_PW);                 // [ch][k][16] f32
     if (tid < HM_CH * 16) {
         const int c = tid >> 4, m = tid & 15;               // component m = 4 q + r sits in table word 36 + 4 k + r of lanes with q
         const uint32_t* tp = a.tab + ((int64_t)(d0 + c) * HM_TABW) * 64 + (m >> 2) * 16;
 #pragma unroll
         for (int k = 0; k < 4; ++k) pwl[(c * 4 + k) * 16 + m] = __builtin_bit_cast(float, tp[(36 + 4 * k + (m & 3)) * 64]);
     }
-    // (NO compiler-visible VMEM load may sit inside the tile loop: it gets an s_waitcnt vmcnt(0), which drains the DMA of
-    //  the next tile in the middle of the step -- an early version lost ~40 % to a dskip load in stage 2; the same goes
-    //  for scratch reloads, hence the LDS-resident constants)
+    // (NO compiler-visible VMEM access may sit inside the tile loop: a load gets an s_waitcnt vmcnt(0), which drains the DMA
+    //  of the next tile in the middle of the step, and the same goes for scratch reloads -- hence the LDS-resident
+    //  constants.  The y stores are inline asm too, and bounds-checked buffer stores so that EVERY S3 issues exactly two.)
     float carry[2][4];                                       // tile-entering state: components 4q..4q+3, valid in lanes a = 0
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) carry[cc][r] = 0.f;
     const int la = lane & 15, lq = lane >> 4;
     const float first_blk = la == 0 ? 1.f : 0.f;
+    const uint64_t y64 = (uint64_t)a.y;
+    const hm_u32x4 ysrd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.B * a.T * a.D * 2), 0x00020000u};
 
-    // VM-counter bookkeeping.  Issue order per step s:  [top] z(s+1)  ...  [stage 3] 2 y stores.  At the top of step s the
-    // tile z(s) (issued at the top of s-1) must have landed: everything but the 2 stores of step s-1 has to retire -- they
-    // only count when step s-1 was a full tile (otherwise they are conditional: wait for them too).
-#if HM_PROFILE      // -DHM_PROFILE=1: wave 0 of workgroup 0 accumulates shader-clock deltas per stage (tools/hm_stage_profile.py)
-    const bool prof = blockIdx.x == 0 && wave == 0;
-    uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-#define HM_STAMP(K) if (prof) { const uint64_t now_ = __builtin_readcyclecounter(); tprof[K] += now_ - tlast; tlast = now_; }
-#else
-#define HM_STAMP(K)
-#endif
-    dma_tile(0);
-#if HM_PROFILE
-    if (prof) tlast = __builtin_readcyclecounter();
-#endif
-    for (int step = 0; step < n_steps; ++step) {
-        const int ri = step / a.n_tiles, tile = step - ri * a.n_tiles;
-        const int b = b0 + ri * a.nb_split;
-        unsigned char* zt = smem + (step & 1) * HM_ZBUF;
-        if (step > 0 && tile != 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        HM_STAMP(0);                                         // [0] waiting for the tile's DMA (and old stores)
-        __syncthreads();                                     // ... everyone's: the tile is visible, step-1 fully consumed
-        HM_STAMP(1);                                         // [1] barrier skew
-        if (step + 1 < n_steps) dma_tile(step + 1);          // its buffer was last read by stage 3 of step-1
-        if (tile == 0) {                                     // rows -2, -1: the halo (or zeros) instead of the clamped row 0
-            if (tid < 2 * 24) {
-                const int r = tid / 24, wq = tid - 24 * r;   // 24 dwords per row: x2 | x1 | v
+    // ================= stage 1: FIR (x1, v), x = x1 * v, bf16 hi | lo plane units; the x2 dwords parked for S3 =================
+    auto stage1 = [&](int step) {
+        const StepInfo s = step_info(step);
+        if (s.tile == 0 && wave == 0) {                      // rows -2, -1: the halo (or zeros) instead of the clamped row 0
+            if (lane < 48) {
+                const int r = lane / 24, wq = lane - 24 * r; // 24 dwords per row: x2 | x1 | v
                 uint32_t v = 0u;
-                if (a.z_halo) v = a.z_halo[((int64_t)b * 2 + r) * (rowbytes / 4) + cg * (HM_ROWB / 4) + wq];
-                *(uint32_t*)(zt + r * HM_ROWB + wq * 4) = v;
+                if (a.z_halo) v = a.z_halo[((int64_t)s.b * 2 + r) * (rowbytes / 4) + cg * (HM_ROWB / 4) + wq];
+                *(uint32_t*)(win + HM_WIN_ROW(r) + wq * 4) = v;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const f32x2_t w10 = firp[4], w11 = firp[5], w12 = firp[6], b1 = firp[7];
+        const f32x2_t w20 = firp[8], w21 = firp[9], w22 = firp[10], b2 = firp[11];
+        // window row r <-> step 64 wave - 2 + r of the tile.  This thread reads rows 8 phl .. 8 phl + 9
+        const unsigned char* zr = win + p * 4;               // x2 +0, x1 +32, v +64
+        unsigned char* xp = x2pw + (step & 1) * HM_X2P_TILE + p * 4;
+#define HM_WR(I) HM_WIN_ROW(8 * phl + (I))
+        if (phl == 0) {                                      // the wave's two history rows of x2
+            *(uint32_t*)(xp + HM_X2P_SLOT(0) * 32) = *(const uint32_t*)(zr + HM_WIN_ROW(0));
+            *(uint32_t*)(xp + HM_X2P_SLOT(1) * 32) = *(const uint32_t*)(zr + HM_WIN_ROW(1));
+        }
+        f32x2_t m2a = bf2_f(*(const uint32_t*)(zr + HM_WR(0) + 32)), m2b = bf2_f(*(const uint32_t*)(zr + HM_WR(0) + 64));
+        f32x2_t m1a = bf2_f(*(const uint32_t*)(zr + HM_WR(1) + 32)), m1b = bf2_f(*(const uint32_t*)(zr + HM_WR(1) + 64));
+        uint32_t hi8[2][4], lo8[2][4];                       // this thread's 8 steps of both channels, bf16 pairs
+        const bool full1 = s.t0 + HM_TT <= a.T;
+        const int n_valid = full1 ? 8 : (int)(a.T - s.t0 - 8 * ph);      // steps of this thread inside the sequence
+        uint32_t hprev = 0u, lprev = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t cx = *(const uint32_t*)(zr + HM_WR(i + 2));
+            const f32x2_t ca = bf2_f(*(const uint32_t*)(zr + HM_WR(i + 2) + 32));
+            const f32x2_t cb = bf2_f(*(const uint32_t*)(zr + HM_WR(i + 2) + 64));
+            // window row 8 phl + i + 2 -> parked slot: i < 6: 8 (i + 2) + phl; i = 6, 7: row 8 (phl + 1) + (i - 6)
+            {
+                const int slot = i < 6 ? 8 * (i + 2) + phl : (phl < 7 ? 8 * (i - 6) + phl + 1 : 64 + (i - 6));
+                *(uint32_t*)(xp + slot * 32) = cx;
+            }
+            const f32x2_t x1c = hm_fma(w12, ca, hm_fma(w11, m1a, hm_fma(w10, m2a, b1)));
+            const f32x2_t vc = hm_fma(w22, cb, hm_fma(w21, m1b, hm_fma(w20, m2b, b2)));
+            f32x2_t x = x1c * vc;
+            if (!full1 && i >= n_valid) { x[0] = 0.f; x[1] = 0.f; }      // past the end: nothing enters the modes
+            const uint32_t hi = pack_bf2(x[0], x[1]);
+            const uint32_t lo = pack_bf2(x[0] - bf_lo(hi), x[1] - bf_hi(hi));
+            // transpose the (channel pair) x (8 steps) block in registers: word i/2 of channel e = steps i-1, i of e
+            if (i & 1) {                                     // v_perm_b32: bytes of {odd step, even step}
+                hi8[0][i >> 1] = __builtin_amdgcn_perm(hi, hprev, 0x05040100u);
+                hi8[1][i >> 1] = __builtin_amdgcn_perm(hi, hprev, 0x07060302u);
+                lo8[0][i >> 1] = __builtin_amdgcn_perm(lo, lprev, 0x05040100u);
+                lo8[1][i >> 1] = __builtin_amdgcn_perm(lo, lprev, 0x07060302u);
+            } else {
+                hprev = hi;
+                lprev = lo;
+            }
+            m2a = m1a; m1a = ca; m2b = m1b; m1b = cb;
+        }
+#undef HM_WR
+        // unit ph of both channels: [hi | lo]
+        unsigned char* x0 = pl + ((step & 1) * HM_CH + 2 * p) * HM_XTCH + ph * HM_UNIT;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            *(hm_u32x4*)(x0 + e * HM_XTCH) = hm_u4(hi8[e][0], hi8[e][1], hi8[e][2], hi8[e][3]);
+            *(hm_u32x4*)(x0 + e * HM_XTCH + 16) = hm_u4(lo8[e][0], lo8[e][1], lo8[e][2], lo8[e][3]);
+        }
+        // every read of the window has returned before the caller refills it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    // ================= stage 2: per channel  E = W.X, y0 = T0.X, block scan, y = y0 + G.S =================
+    auto stage2 = [&](int step) {
+        const StepInfo s = step_info(step);
+        if (s.tile == 0) {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) carry[cc][r] = 0.f;        // a new sequence starts from a zero state
-            __syncthreads();
         }
-        const int64_t t0 = (int64_t)tile * HM_TT;
-
-        // ================= stage 1: FIR (x1, v), x = x1 * v, bf16 hi / lo planes written transposed =================
-        {
-            const int tl0 = ph * 8;
-            const f32x2_t w10 = firp[4], w11 = firp[5], w12 = firp[6], b1 = firp[7];
-            const f32x2_t w20 = firp[8], w21 = firp[9], w22 = firp[10], b2 = firp[11];
-            // buffer row r <-> local step r - 2.  This thread reads rows 8 ph .. 8 ph + 9: slots 9 ph + {0..7}, 9 ph + {9, 10}
-            const unsigned char* zr = zt + (9 * ph) * HM_ROWB + p * 4;  // x2 +0, x1 +32, v +64
-#define HM_ROWOFF(I) (((I) < 8 ? (I) : (I) + 1) * HM_ROWB)              /* byte offset of the thread's I-th row, I = 0..9 */
-            f32x2_t m2a = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(0) + 32)), m2b = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(0) + 64));
-            f32x2_t m1a = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(1) + 32)), m1b = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(1) + 64));
-            uint32_t hi8[2][4], lo8[2][4];                              // this thread's 8 steps of both channels, bf16 pairs
-            const bool full1 = t0 + HM_TT <= a.T;
-            const int n_valid = full1 ? 8 : (int)(a.T - t0 - tl0);      // steps of this thread inside the sequence
-            uint32_t hprev = 0u, lprev = 0u;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2_t ca = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(i + 2) + 32));
-                const f32x2_t cb = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(i + 2) + 64));
-                const f32x2_t x1c = hm_fma(w12, ca, hm_fma(w11, m1a, hm_fma(w10, m2a, b1)));
-                const f32x2_t vc = hm_fma(w22, cb, hm_fma(w21, m1b, hm_fma(w20, m2b, b2)));
-                f32x2_t x = x1c * vc;
-                if (!full1 && i >= n_valid) { x[0] = 0.f; x[1] = 0.f; }  // past the end: nothing enters the modes
-                const uint32_t hi = pack_bf2(x[0], x[1]);
-                const uint32_t lo = pack_bf2(x[0] - bf_lo(hi), x[1] - bf_hi(hi));
-                // transpose the (channel pair) x (8 steps) block in registers: word i/2 of channel e = steps i-1, i of e
-                if (i & 1) {                                            // v_perm_b32: bytes of {odd step, even step}
-                    hi8[0][i >> 1] = __builtin_amdgcn_perm(hi, hprev, 0x05040100u);
-                    hi8[1][i >> 1] = __builtin_amdgcn_perm(hi, hprev, 0x07060302u);
-                    lo8[0][i >> 1] = __builtin_amdgcn_perm(lo, lprev, 0x05040100u);
-                    lo8[1][i >> 1] = __builtin_amdgcn_perm(lo, lprev, 0x07060302u);
-                } else {
-                    hprev = hi;
-                    lprev = lo;
-                }
-                m2a = m1a; m1a = ca; m2b = m1b; m1b = cb;
-            }
-            // one 16-byte chunk (8 steps) per channel and plane, at its swizzled position
-            unsigned char* x0 = xt + (2 * p) * HM_XTCH + HM_PCH(ph) * 16;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                *(hm_u32x4*)(x0 + e * HM_XTCH) = hm_u4(hi8[e][0], hi8[e][1], hi8[e][2], hi8[e][3]);
-                *(hm_u32x4*)(x0 + e * HM_XTCH + HM_PLANE) = hm_u4(lo8[e][0], lo8[e][1], lo8[e][2], lo8[e][3]);
-            }
-        }
-        HM_STAMP(2);                                         // [2] DMA issue + stage 1
-        __syncthreads();
-        HM_STAMP(1);
-
-        // ================= stage 2: per channel  E = W.X, y0 = T0.X, block scan, y = y0 + G.S =================
+        // (the two channels one after the other: taking both through the phases together -- two independent scan chains per
+        //  phase -- measured 4 % / 20 % SLOWER at 8 x 8,193 / 131 k, profiles/r02_hyena_mfma_notes.txt)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            unsigned char* xc = xt + (2 * wave + cc) * HM_XTCH;
-            // B operands: lane (a, kg) holds steps 32 a + 8 kg .. + 7 = plane chunk 4 a + kg
-            const bf16x8_t xh = *(const bf16x8_t*)(xc + HM_PCH(4 * la + lq) * 16);
-            const bf16x8_t xl = *(const bf16x8_t*)(xc + HM_PLANE + HM_PCH(4 * la + lq) * 16);
+            unsigned char* xc = pl + ((step & 1) * HM_CH + 2 * wave + cc) * HM_XTCH;
+            const bf16x8_t xh = *(const bf16x8_t*)(xc + (4 * la + lq) * HM_UNIT);
+            const bf16x8_t xl = *(const bf16x8_t*)(xc + (4 * la + lq) * HM_UNIT + 16);
             const uint32_t* t_ = tb[cc];
 #define HM_FRAG(BASE) __builtin_bit_cast(bf16x8_t, hm_u4(t_[(BASE)], t_[(BASE) + 1], t_[(BASE) + 2], t_[(BASE) + 3]))
             const hm_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            // block aggregates (W = hi + mid + lo, X = hi + lo; the lo*lo term is below 2^-33)
-            hm_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 8), xh, zero4, 0, 0, 0);      // W_lo  . X_hi
-            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 4), xl, e, 0, 0, 0);                   // W_mid . X_lo
-            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 4), xh, e, 0, 0, 0);                   // W_mid . X_hi
-            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16), xl, e, 0, 0, 0);                       // W_hi  . X_lo
-            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16), xh, e, 0, 0, 0);                       // W_hi  . X_hi
-            // block Toeplitz, two 16-row tiles (T0 = hi + lo)
+            hm_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 8), xh, zero4, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 4), xl, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16 + 4), xh, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16), xl, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(16), xh, e, 0, 0, 0);
             hm_f32x4 yv[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                hm_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt + 4), xh, zero4, 0, 0, 0);   // T0_lo . X_hi
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt), xl, acc, 0, 0, 0);                  // T0_hi . X_lo
-                yv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt), xh, acc, 0, 0, 0);               // T0_hi . X_hi
+                hm_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt + 4), xh, zero4, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt), xl, acc, 0, 0, 0);
+                yv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HM_FRAG(8 * mt), xh, acc, 0, 0, 0);
             }
 #undef HM_FRAG
-            // scan over the 16 blocks (lanes a = lane & 15 of each 16-lane row; this lane: modes 2q, 2q+1 as re, im, re, im)
             HM_FENCE_NOP();
-            float s[4] = {e[0], e[1], e[2], e[3]};
-            const hm_f32x4* pwc = (const hm_f32x4*)(pwl + (2 * wave + cc) * 64) + lq;      // [k] -> + 4 k
-            {   // the state entering the tile goes into block 0's aggregate: E[0] += p^32 * carry
+            float sv[4] = {e[0], e[1], e[2], e[3]};
+            const hm_f32x4* pwc = (const hm_f32x4*)(pwl + (2 * wave + cc) * 64) + lq;
+            {
                 const hm_f32x4 P = pwc[0];
-                s[0] += first_blk * (P[0] * carry[cc][0] - P[1] * carry[cc][1]);
-                s[1] += first_blk * (P[0] * carry[cc][1] + P[1] * carry[cc][0]);
-                s[2] += first_blk * (P[2] * carry[cc][2] - P[3] * carry[cc][3]);
-                s[3] += first_blk * (P[2] * carry[cc][3] + P[3] * carry[cc][2]);
+                sv[0] += first_blk * (P[0] * carry[cc][0] - P[1] * carry[cc][1]);
+                sv[1] += first_blk * (P[0] * carry[cc][1] + P[1] * carry[cc][0]);
+                sv[2] += first_blk * (P[2] * carry[cc][2] - P[3] * carry[cc][3]);
+                sv[3] += first_blk * (P[2] * carry[cc][3] + P[3] * carry[cc][2]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const hm_f32x4 P = pwc[4 * k];
-                const float u0 = hm_dpp_shr(s[0], 1 << k), u1 = hm_dpp_shr(s[1], 1 << k);
-                const float u2 = hm_dpp_shr(s[2], 1 << k), u3 = hm_dpp_shr(s[3], 1 << k);
-                s[0] += P[0] * u0 - P[1] * u1;
-                s[1] += P[0] * u1 + P[1] * u0;
-                s[2] += P[2] * u2 - P[3] * u3;
-                s[3] += P[2] * u3 + P[3] * u2;
+                const float u0 = hm_dpp_shr(sv[0], 1 << k), u1 = hm_dpp_shr(sv[1], 1 << k);
+                const float u2 = hm_dpp_shr(sv[2], 1 << k), u3 = hm_dpp_shr(sv[3], 1 << k);
+                sv[0] += P[0] * u0 - P[1] * u1;
+                sv[1] += P[0] * u1 + P[1] * u0;
+                sv[2] += P[2] * u2 - P[3] * u3;
+                sv[3] += P[2] * u3 + P[3] * u2;
             }
-            // state ENTERING each block: the inclusive scan shifted by one block, the tile's entering state in block 0
             float st[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st[r] = hm_dpp_shr(s[r], 1) + first_blk * carry[cc][r];
-            // next tile's entering state = inclusive value of block 15.  Only lane a = 0 of a row ever uses it (first_blk masks the
-            // others): a row rotate by one lane puts block 15's value there -- plain DPP, no LDS crossbar round trip
+            for (int r = 0; r < 4; ++r) st[r] = hm_dpp_shr(sv[r], 1) + first_blk * carry[cc][r];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s[r]), 0x121, 0xf, 0xf, false));
-            // y += G . S_start on the bf16 matrix core with both operands split hi + lo (G_hi S_hi + G_hi S_lo + G_lo S_hi,
-            // 2^-17): K = 32 = per k-group [S_hi of components 4 kg .. 4 kg + 3 | S_lo of the same]
+                carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[r]), 0x121, 0xf, 0xf, false));
             {
                 const uint32_t h01 = pack_bf2(st[0], st[1]), h23 = pack_bf2(st[2], st[3]);
                 const uint32_t l01 = pack_bf2(st[0] - bf_lo(h01), st[1] - bf_hi(h01));
@@ -351,75 +361,117 @@ __global__ __launch_bounds__(512, 1) void hyena_mfma_kernel(HmArgs a) {
                                                                     sb, yv[mt], 0, 0, 0);
                 }
             }
-            // (y + x1v D)^T (filter.D sits on T0's diagonal) over this channel's planes: lane (a, q) holds steps
-            // 32 a + 16 mt + 4 q + 0..3.  Every plane read of
-            // this wave precedes these stores in program order, and one wave's LDS operations execute in order.
             HM_FENCE_NOP();
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) *(hm_f32x4*)(xc + HM_YCH(8 * la + 4 * mt + lq) * 16) = yv[mt];
+            for (int mt = 0; mt < 2; ++mt) *(hm_f32x4*)(xc + (4 * la + 2 * mt + (lq >> 1)) * HM_UNIT + (lq & 1) * 16) = yv[mt];
             HM_FENCE();
         }
-        HM_STAMP(3);                                         // [3] stage 2
-        __syncthreads();
-        HM_STAMP(1);
+    };
 
-        // ================= stage 3: FIR (x2), gate, store =================
-        {
-            const f32x2_t w00 = firp[0], w01 = firp[1], w02 = firp[2], b0f = firp[3];
-            const unsigned char* zr = zt + (9 * ph) * HM_ROWB + p * 4;
-            f32x2_t m2 = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(0))), m1 = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(1)));
-            // (y + x1v D)^T of this thread's 8 steps: chunks 2 ph, 2 ph + 1 of both channels
-            hm_f32x4 yq[2][2];
+    // ================= stage 3: FIR (x2), gate, store =================
+    auto stage3 = [&](int step) {
+        const StepInfo s = step_info(step);
+        unsigned char* x2b = x2pw + (step & 1) * HM_X2P_TILE;
+        const f32x2_t w00 = firp[0], w01 = firp[1], w02 = firp[2], b0f = firp[3];
+        unsigned char* zr = x2b + p * 4;
+        // parked row 8 phl + i of this wave (S1 of the same wave put it there two intervals ago; rows 0, 1 are the history)
+#define HM_X2R(I) (((I) < 8 ? 8 * (I) + phl : (phl < 7 ? 8 * ((I) - 8) + phl + 1 : 64 + ((I) - 8))) * 32)
+        // all ten x2 rows of this thread FIRST: the outputs below are staged in these very rows (rows 8 phl + 8, + 9 are the
+        // next phase's first two output rows; one wave's LDS operations execute in order)
+        uint32_t xr[10];
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+        for (int i = 0; i < 10; ++i) xr[i] = *(const uint32_t*)(zr + HM_X2R(i));
+        // (y + x1v D)^T of this thread's 8 steps: unit ph of both channels
+        hm_f32x4 yq[2][2];
+        const unsigned char* y0 = pl + ((step & 1) * HM_CH + 2 * p) * HM_XTCH + ph * HM_UNIT;
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    yq[e][k] = *(const hm_f32x4*)(xt + (2 * p + e) * HM_XTCH + HM_YCH(2 * ph + k) * 16);
-            const bool full = t0 + HM_TT <= a.T;                        // (wave-uniform: the usual case is branch-free)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2_t c = bf2_f(*(const uint32_t*)(zr + HM_ROWOFF(i + 2)));
-                const f32x2_t x2f = hm_fma(w02, c, hm_fma(w01, m1, hm_fma(w00, m2, b0f)));
-                m2 = m1;
-                m1 = c;
-                const f32x2_t yc = {yq[0][i >> 2][i & 3], yq[1][i >> 2][i & 3]};      // y_conv + x1v * D
-                const f32x2_t o = yc * x2f;
-                // staged in the x1 slot of the row (dead since stage 1; stage 3 reads only x2 slots): the 8 pairs of a wave
-                // complete the row's 32 output bytes
-                *(uint32_t*)(const_cast<unsigned char*>(zr) + HM_ROWOFF(i + 2) + 32) = pack_bf2(o[0], o[1]);
-            }
-            // the wave's 64 rows x 32 B, 16 B per lane: two global_store_dwordx4 per wave instead of eight dword stores
-            // (the y tail was store-ISSUE bound).  Same wave wrote the staging slots: LDS executes a wave's operations in order.
-            // (compiler fence: the dword stores above and the 16-byte loads below are differently typed accesses to the same
-            //  bytes -- without it the loads may be scheduled first)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int wrow0 = (tid >> 6) * 64;                           // first local step of this wave's rows
+            for (int k = 0; k < 2; ++k) yq[e][k] = *(const hm_f32x4*)(y0 + e * HM_XTCH + k * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]),
+                     "+v"(xr[6]), "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]) :: "memory");
+        f32x2_t m2 = bf2_f(xr[0]), m1 = bf2_f(xr[1]);
 #pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-                const int rr = hs * 32 + (lane >> 1);                    // local row 0..63 of the wave, half (lane & 1)
-                const int r = wrow0 + rr + 2;                            // buffer row
-                const hm_u32x4 v = *(const hm_u32x4*)(zt + HM_SLOT(r) * HM_ROWB + 32 + (lane & 1) * 16);
-                const int64_t t = t0 + wrow0 + rr;
-                if (full || t < a.T)
-                    *(hm_u32x4*)((unsigned char*)a.y + (((int64_t)b * a.T + t) * a.D + d0) * 2 + (lane & 1) * 16) = v;
-            }
+        for (int i = 0; i < 8; ++i) {
+            const f32x2_t c = bf2_f(xr[i + 2]);
+            const f32x2_t x2f = hm_fma(w02, c, hm_fma(w01, m1, hm_fma(w00, m2, b0f)));
+            m2 = m1;
+            m1 = c;
+            const f32x2_t yc = {yq[0][i >> 2][i & 3], yq[1][i >> 2][i & 3]};      // y_conv + x1v * D
+            const f32x2_t o = yc * x2f;
+            // staged in the x2 slot of the step's own row: the 8 pairs of a wave complete the row's 32 output bytes
+            *(uint32_t*)(zr + HM_X2R(i + 2)) = pack_bf2(o[0], o[1]);
         }
-        HM_STAMP(4);                                         // [4] stage 3
+#undef HM_X2R
+        // the wave's 64 rows x 32 B, 16 B per lane: two 16-byte stores per wave and tile (the y tail of the first version was
+        // store-ISSUE bound with eight dword stores).  Same wave wrote the staging rows: LDS executes a wave's operations in
+        // order; the fence keeps the differently typed accesses to the same bytes ordered for the compiler.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool full = s.t0 + HM_TT <= a.T;
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int rr = hs * 32 + (lane >> 1);            // local step 0..63 of the wave, half (lane & 1)
+            const int row = rr + 2;
+            const hm_u32x4 v = *(const hm_u32x4*)(x2b + HM_X2P_SLOT(row) * 32 + (lane & 1) * 16);
+            const int64_t t = s.t0 + 64 * wave + rr;
+            // bounds-checked buffer store: rows past the end of the sequence get an offset beyond num_records and are dropped,
+            // so that the VM counter sees exactly two stores per S3
+            const uint32_t off = (full || t < a.T) ? (uint32_t)((((int64_t)s.b * a.T + t) * a.D + d0) * 2 + (lane & 1) * 16) : 0xfffffff0u;
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(ysrd) : "memory");
+        }
+    };
+
+    // ---- the pipeline.  VM queue of a wave per interval, in issue order: 2 y stores (S3), 7 DMA pieces of window(k+2); it
+    //      retires in order.  Before S1(k+1): window(k+1), issued last in the previous interval, must have landed -- this
+    //      interval's 2 stores may be in flight.  At the head of the stream (no S3 yet) the count does not hold: wait for all.
+#if HM_PROFILE      // -DHM_PROFILE=1: wave 0 of workgroup 0 accumulates shader-clock deltas per role (tools/hm_stage_profile.py)
+#ifndef HM_PROF_WAVE
+#define HM_PROF_WAVE 0
+#endif
+    const bool prof = blockIdx.x == 0 && wave == HM_PROF_WAVE;
+    uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define HM_STAMP(K) if (prof) { const uint64_t now_ = __builtin_readcyclecounter(); tprof[K] += now_ - tlast; tlast = now_; }
+#else
+#define HM_STAMP(K)
+#endif
+    dma_win(0);
+    __syncthreads();                                         // FIR taps and scan powers are in LDS
+#if HM_PROFILE
+    if (prof) tlast = __builtin_readcyclecounter();
+#endif
+#ifndef HM_ORDER
+#define HM_ORDER 0                          // 0: waves 4-7 run S2 first (default), 1: no wave does, 2: all do (measurement builds)
+#endif
+    const bool mfma_first = HM_ORDER == 0 ? wave >= 4 : HM_ORDER == 2;
+    for (int k = -1; k <= n_steps; ++k) {
+        if (mfma_first && k >= 0 && k < n_steps) { stage2(k); HM_STAMP(3); }
+        if (k >= 1) { stage3(k - 1); HM_STAMP(4); }
+        if (k + 1 < n_steps) {
+            if (k >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HM_STAMP(0);
+            stage1(k + 1);
+            if (k + 2 < n_steps) dma_win(k + 2);
+            HM_STAMP(2);
+        }
+        if (!mfma_first && k >= 0 && k < n_steps) { stage2(k); HM_STAMP(3); }
+        __syncthreads();                                     // planes(k+1) -> S2(k+1), y^T(k) -> S3(k)
+        HM_STAMP(1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if HM_PROFILE
     if (prof && lane == 0) {                                 // (timing build only: overwrites the first words of y)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int k = 0; k < 5; ++k) ((float*)a.y)[k] = (float)tprof[k];
         ((float*)a.y)[5] = (float)n_steps;
     }
 #endif
 #undef HM_STAMP
-#undef HM_ROWOFF
 }
 
 extern "C" int evo_hyena_mfma(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* dskip,
                               const void* table, void* y, int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream) {
     if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0 || D != n_heads * 128) return -1;
+    if (B * T * D * 2 >= 0xfffffff0ll) return -1;                       // y goes through a 32-bit bounded buffer descriptor
     const int64_t groups = D / HM_CH;
     // workgroups = groups x nb_split, ~one per CU: a workgroup walks batch rows b0, b0 + nb_split, ... of its channels
     int64_t nb_split = (256 + groups - 1) / groups;

@@ -205,6 +205,7 @@ class StripedHyena(nn.Module):
                 f._fir_w = f.short_filter_weight.data.reshape(3 * D, self.short_filter_length).contiguous()
                 f._poles = f.poles.data.reshape(D, self.state_size, 2).float().contiguous()
                 f._residues = f.residues.data.reshape(D, self.state_size, 2).float().contiguous()
+                f._mfma = None                   # grouped projection + operand table of the matrix-core operator: built on first use
         self._packed = True
 
     # ------------------------------------------------------------------ caches
@@ -294,6 +295,27 @@ class StripedHyena(nn.Module):
             a = ops.mlp_gate(n2, blk.mlp._w12)
         ops.linear_residual_(x2d, a, blk.mlp._w3)
 
+    def _mfma_hyena_ok(self, B: int, T: int) -> bool:
+        """The single-pass matrix-core operator serves plain scoring calls (no cache, no mask) on the HIP backend when the
+        shape fits its launch contract (include/evo_mi355x.h: evo_hyena_mfma); everything else takes the modal kernels."""
+        ops = self.ops
+        D, H = self.hidden_size, self.num_heads
+        if not getattr(ops, "hyena_mfma", False) or not hasattr(ops, "hyena_mfma_prefill") or D != H * 128:
+            return False
+        groups = D // 16
+        split = min(B, (256 + groups - 1) // groups)
+        return B * T >= 1024 and B * T * D * 2 < 0xfffffff0 and (groups * split) % 8 == 0
+
+    def _mfma_pack(self, blk):
+        f = blk.filter
+        if getattr(f, "_mfma", None) is None or f._mfma[0].device != blk.projections.weight.device:
+            from ..hyena_tables import group_permutation, mfma_operand_table
+            w, b = blk.projections.weight.data, blk.projections.bias
+            perm = group_permutation(self.hidden_size, self.num_heads, w.device)
+            table = mfma_operand_table(f._poles, f._residues, f.D.data)
+            f._mfma = (w[perm].contiguous(), None if b is None else b.data[perm].contiguous(), table)
+        return f._mfma
+
     def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams], mask=None):
         """`mask` = (flat [B*T,1] bf16, [B,T] uint8) of upstream's padding_mask, or None: the projections output, the FIR
         output and the mixer output + residual are multiplied by it, as upstream's ParallelGatedConvBlock /
@@ -306,6 +328,13 @@ class StripedHyena(nn.Module):
             y = ops.hyena_decode_fused(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias,
                                        cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
                                        f._poles, f._residues, f.D, H)
+        elif cache is None and mask is None and self._mfma_hyena_ok(B, T):
+            # scoring shapes: the whole operator in ONE pass on the matrix cores (csrc/hyena_mfma.hip).  It wants the
+            # projection's output columns grouped [16-channel group][x2 | x1 | v]: the projection GEMM writes that layout
+            # directly from a row-permuted copy of its weight (built once per layer, with the layer's MFMA operand table).
+            wg, bg, table = self._mfma_pack(blk)
+            z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, wg, bg)
+            y = ops.hyena_mfma_prefill(z.view(B, T, 3 * D), f._fir_w, f.short_filter_bias, f.D, table, H).view(B * T, D)
         else:
             z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
             if mask is not None:
