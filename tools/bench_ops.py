@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--seg-len", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--attn-T", type=int, default=16385)
+    ap.add_argument("--attn-sweep", action="store_true")
+    ap.add_argument("--fft", action="store_true", help="with --only hyena: also time a rocFFT long convolution of the same size")
     args = ap.parse_args()
     from evo_amd.ops import KernelTimer, default_ops
     ops = default_ops()
@@ -64,10 +66,33 @@ def main():
             except Exception as e:  # noqa: BLE001
                 ops.timer = None
                 print(f"[{tag}] hyena_mfma B={B} T={T}: FAILED {type(e).__name__}: {e}")
+            if args.only == "hyena" and args.fft:
+                # the north-star's FFT form as a DATA POINT: the long convolution alone (no FIR, no gates, no layout change) by
+                # rocFFT through torch.fft in fp32 -- rfft of x1*v [B, D, n], times the filter's spectrum, irfft.  n = 2T rounded
+                # up to a power of two, as the reference's fftconv pads.
+                n = 1 << (2 * T - 1).bit_length()
+                Bc = B if T < 20000 else 1
+                x = torch.randn(Bc, D, T, device=dev)
+                Hf = torch.fft.rfft(torch.randn(D, T, device=dev), n=n)
+                def fftconv():
+                    return torch.fft.irfft(torch.fft.rfft(x, n=n) * Hf, n=n)[..., :T]
+                for _ in range(2):
+                    fftconv()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    fftconv()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.reps
+                print(f"[{tag}] rocFFT fp32 long convolution alone B={Bc} T={T} n={n}: {ms:.3f}ms "
+                      f"(whole operator: three launches {tot:.3f}ms)")
+                del x, Hf
             del z
     if args.only in ("", "attn"):
-        for T in (8193, args.attn_T):
-            Bq = 8 if T == 8193 else 1
+        shapes = [(8, 8193), (1, args.attn_T)] + ([(1, 8193), (2, 8193), (4, 8193), (8, 4097), (8, 16385), (2, 32769)] if args.attn_sweep else [])
+        for (Bq, T) in shapes:
             qkv = rn(Bq, T, 3, H, 128).bfloat16()
             for _ in range(1):
                 ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
