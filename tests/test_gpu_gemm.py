@@ -76,6 +76,29 @@ def test_linear_mfma_rejects_unsupported_shapes():
     with pytest.raises(RuntimeError):
         ops.linear_mfma(x, w)                                            # N % 256 != 0
 
+@pytest.mark.parametrize("M,N,K,bias,res", [(8192 + 77, 4096, 128, False, False), (20000, 2048, 192, True, False),
+                                            (16384, 4096, 4096, True, True), (65544, 512, 256, False, True),
+                                            (33000, 1024, 1024, False, False)])
+def test_linear_mfma_persistent_stream_many_tiles_per_workgroup(M, N, K, bias, res):
+    """More output tiles than workgroups (514 ... 1,056 tiles on 256 CUs): every workgroup of the persistent kernel walks
+    several tiles, so the (tile, k-step) stage stream crosses tile boundaries -- the fetch cursor switches tiles two
+    stages ahead of the MFMAs (every 2 or 3 stages at K = 128 / 192), the epilogue runs between two tiles of one stream,
+    the ragged last M tile sits in the middle of some workgroup's list."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if res else None
+    want = _ref(x, w, b, r)
+    got = ops.linear_mfma(x, w, b, r.clone() if res else None)
+    err = (got.double() - want).abs()
+    tol = want.abs() * 2.0 ** -8 + 1e-3
+    bad = err > tol
+    assert not bool(bad.any()), f"{int(bad.sum())} elements off, first at {bad.nonzero()[0].tolist()}, max err {err.max().item():.3e}"
+    again = ops.linear_mfma(x, w, b, r.clone() if res else None)
+    assert torch.equal(got, again)                                       # no order-dependent accumulation anywhere
+
 
 @pytest.mark.parametrize("M", [4096 + 8, 8192 + 1, 4096 + 16, 4096 + 17, 4096])
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual", "mfma_bias", "mfma_residual"])
