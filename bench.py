@@ -132,7 +132,10 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("hyena_mfma_kernel", B, T),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                 "tensor_bytes_per_launch": io_live.get("mfma"),
-                "operator_frac": ach / HBM_PEAK_GBS, "modal_three_launch": three}
+                "operator_frac": ach / HBM_PEAK_GBS, "modal_three_launch": three,
+                "note": "round 1 reported hyena_apply_kernel, ONE of the operator's three launches (frac 0.55, operator_frac 0.33 over "
+                        "all three); this launch IS the whole operator (z read once, y written once): compare frac with "
+                        "modal_three_launch.operator_frac of the same run"}
     achieved = alg_bytes / (ksum["hyena_apply"][1] * 1e-3) / 1e9
     op_ms = ksum["hyena_apply"][1] + ksum["hyena_seg_state"][1] + ksum["hyena_carry_scan"][1]
     return {"kernel": "hyena_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -286,6 +289,14 @@ def main():
     kernels["attn_fwd"]["mfma_frac"] = kernels["attn_fwd"]["tflops"] / MFMA_BF16_PEAK_TFLOPS
     # dense layers: "gemm_mfma" = the hand-written kernel (csrc/gemm.hip), "gemm" = hipBLASLt (only with EVO_AMD_GEMM=hipblaslt)
     gemm_ms = sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm", "gemm_mfma") if k in ksum)
+    # the dense layers (87 % of the step) against the dense bf16 MFMA peak: 2 * M * N * K summed over the launches of a step
+    dense_flop = 2.0 * B * T * 4096 * (12288 + 4096 + 22016 + 11008) * 32      # proj/Wqkv, out, l1|l2 (padded), l3 (padded K)
+    roofline_dense = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "achieved": dense_flop / (gemm_ms * 1e-3) / 1e12, "frac": dense_flop / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                      "kernels": "hipBLASLt MT256x256x64 (plain Hyena / MLP GEMMs) + gemmr_bf16_kernel (attention projections)"
+                      if "gemm" in ksum else "gemmr_bf16_kernel (csrc/gemm.hip)", "ms_per_step": gemm_ms,
+                      "note": "2.5 PFLOP/s is the dense peak; the part is power-limited: both kernels run their MFMA pipes 82-85 % busy "
+                              "at 1.6-1.7 GHz (profiles/r02_gemm_notes.txt)"}
     out = {
         "metric": "nucleotides/sec forward scoring, evo-1 7B", "value": value, "unit": "nt/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -297,7 +308,7 @@ def main():
                    "batch_per_gpu": B, "nt": nt, "tokens_per_seq": T,
                    "parallelism": "independent batches per GPU" if n_gpus > 1 else "single GPU"},
         "model_tflops": flops_per_token(T) * B * T / (dt / args.steps) / 1e12,
-        "roofline": roofline, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
+        "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
     }
     # ------------------------------------------------------------------ the same step with EVERY dense layer hand-written

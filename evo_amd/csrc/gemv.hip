@@ -247,6 +247,31 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 #pragma unroll
         for (int r = 0; r < GV_R; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[GV_R + r] = ld_stream(wrow[r] + lane + 64); }
     }
+    // the epilogue's operands (this lane's channel x batch row: FIR taps / state / bias of x2, x1, v, the 8 poles, residues and
+    // modal states, D) are requested NOW, behind the first weight trip: they do not depend on the dot products, and fetched
+    // at the end they were a ~2 us dependent-latency tail per wave with nothing left to overlap it
+    const bool ep_lane = lane < 2 * M;
+    const int ep_e = lane & 1, ep_m = ep_lane ? lane >> 1 : 0;
+    const int ep_dch = h * HDc + j0 + ep_e;
+    uint16_t pf_bias[3], pf_fw[3][3], pf_fb[3], pf_fs[3][2], pf_dk = 0;
+    float2 pf_p[NSc], pf_r[NSc], pf_s[NSc];
+    if (ep_lane) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int c = h * 3 * HDc + g * HDc + j0 + ep_e;
+            pf_bias[g] = bias[c];
+            pf_fw[g][0] = fir_w[c * 3]; pf_fw[g][1] = fir_w[c * 3 + 1]; pf_fw[g][2] = fir_w[c * 3 + 2];
+            pf_fb[g] = fir_b[c];
+            const uint16_t* fs = fir_state + ((int64_t)ep_m * 3 * D + c) * 2;
+            pf_fs[g][0] = fs[0]; pf_fs[g][1] = fs[1];
+        }
+        const float2* st = (const float2*)iir_state + ((int64_t)ep_m * D + ep_dch) * NSc;
+        const float2* pp = (const float2*)poles + (int64_t)ep_dch * NSc;
+        const float2* rp = (const float2*)residues + (int64_t)ep_dch * NSc;
+#pragma unroll
+        for (int sI = 0; sI < NSc; ++sI) { pf_p[sI] = pp[sI]; pf_r[sI] = rp[sI]; pf_s[sI] = st[sI]; }
+        pf_dk = dskip[ep_dch];
+    }
     float inv[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -308,8 +333,8 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
-    if (lane >= 2 * M) return;
-    const int e = lane & 1, m = lane >> 1;                       // this lane: channel j0 + e of batch row m
+    if (!ep_lane) return;
+    const int e = ep_e, m = ep_m;                                // this lane: channel j0 + e of batch row m
     float f[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -319,29 +344,27 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 #pragma unroll
             for (int ee = 0; ee < 2; ++ee) d = (m == mm && e == ee) ? acc[2 * g + ee][mm] : d;
         const int c = h * 3 * HDc + g * HDc + j0 + e;            // channel in the 3D row
-        const uint16_t zraw = f_to_bf(d + bf_to_f(bias[c]));     // what the unfused projection stores
+        const uint16_t zraw = f_to_bf(d + bf_to_f(pf_bias[g]));  // what the unfused projection stores
         uint16_t* fs = fir_state + ((int64_t)m * 3 * D + c) * 2;
-        const float o0 = bf_to_f(fs[0]), o1 = bf_to_f(fs[1]);
-        f[g] = fmaf(bf_to_f(fir_w[c * 3 + 2]), bf_to_f(zraw),
-                    fmaf(bf_to_f(fir_w[c * 3 + 1]), o1, fmaf(bf_to_f(fir_w[c * 3]), o0, bf_to_f(fir_b[c]))));
-        fs[0] = fs[1];
+        const float o0 = bf_to_f(pf_fs[g][0]), o1 = bf_to_f(pf_fs[g][1]);
+        f[g] = fmaf(bf_to_f(pf_fw[g][2]), bf_to_f(zraw),
+                    fmaf(bf_to_f(pf_fw[g][1]), o1, fmaf(bf_to_f(pf_fw[g][0]), o0, bf_to_f(pf_fb[g]))));
+        fs[0] = pf_fs[g][1];
         fs[1] = zraw;
     }
-    const int dch = h * HDc + j0 + e;
+    const int dch = ep_dch;
     const float xv = f[1] * f[2];
     float2* st = (float2*)iir_state + ((int64_t)m * D + dch) * NSc;
-    const float2* pp = (const float2*)poles + (int64_t)dch * NSc;
-    const float2* rp = (const float2*)residues + (int64_t)dch * NSc;
     float accy = 0.f;
 #pragma unroll
     for (int s = 0; s < NSc; ++s) {
-        const float2 p = pp[s], r = rp[s], sv = st[s];
+        const float2 p = pf_p[s], r = pf_r[s], sv = pf_s[s];
         const float nr = fmaf(p.x, sv.x, fmaf(-p.y, sv.y, xv));
         const float ni = fmaf(p.x, sv.y, p.y * sv.x);
         st[s] = make_float2(nr, ni);
         accy = fmaf(r.x, nr, fmaf(-r.y, ni, accy));
     }
-    y[(int64_t)m * D + dch] = f_to_bf(fmaf(xv, bf_to_f(dskip[dch]), accy) * f[0]);
+    y[(int64_t)m * D + dch] = f_to_bf(fmaf(xv, bf_to_f(pf_dk), accy) * f[0]);
 }
 
 // ---- gated MLP input, decode form: a[m][n] = gelu(x_m . W1_n) * (x_m . W2_n) with W12 = [W1; W2] ([2I, K]).  Same
@@ -356,6 +379,18 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
     if (n0 >= I) return;
+    const uint4* wrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int64_t n = n0 + (r & 1) < I ? n0 + (r & 1) : I - 1;
+        wrow[r] = w + ((r >> 1) * (int64_t)I + n) * nvec;
+    }
+    // first trip's weights before the norm pass, every later trip one ahead (see gemv_norm_kernel)
+    uint4 wa[8];
+    if (lane + 64 < nvec) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[4 + r] = ld_stream(wrow[r] + lane + 64); }
+    }
     float inv[M];
     if (NORM) {
 #pragma unroll
@@ -382,12 +417,6 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
         return o;
     };
-    const uint4* wrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int64_t n = n0 + (r & 1) < I ? n0 + (r & 1) : I - 1;
-        wrow[r] = w + ((r >> 1) * (int64_t)I + n) * nvec;
-    }
     float acc[4][M];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -395,14 +424,21 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     int v = lane;
     for (; v + 64 < nvec; v += 128) {
-        uint4 w0[4], w1[4];
+        uint4 wb[8];
+        const bool more = v + 128 + 64 < nvec;
+        if (more) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { w0[r] = ld_stream(wrow[r] + v); w1[r] = ld_stream(wrow[r] + v + 64); }
+            for (int r = 0; r < 4; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[4 + r] = ld_stream(wrow[r] + v + 192); }
+        }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 x0 = xin(m, v), x1 = xin(m, v + 64);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(wa[4 + r], x1, dot8(wa[r], x0, acc[r][m]));
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wa[r] = wb[r];
         }
     }
     for (; v < nvec; v += 64) {
