@@ -176,6 +176,8 @@ def test_hyena_prefill_matches_oracle(ops, B, T, D, H, seg):
     (1, 513, 4096, 32),          # BASELINE configs[0] length at the real width
     (2, 8193, 256, 2),           # BASELINE configs[1] length: 17 tiles
     (1, 3000, 128, 1),
+    (40, 300, 128, 1),           # more batch rows than row streams (8 groups x 32): workgroups walk 1 or 2 rows each
+    (3, 1100, 256, 2),           # three row streams of three tiles; the pipeline crosses a row boundary mid-stream
 ])
 def test_hyena_mfma_single_pass_matches_oracle(ops, B, T, D, H):
     """evo_hyena_mfma (block Toeplitz + aggregates on bf16 MFMA, fp32 block scan, carry on fp32 MFMA) vs the fp64
