@@ -1,0 +1,37 @@
+"""Random-shape comparison of evo_hyena_mfma with the three-launch modal path (itself oracle-checked), with and without a
+halo: the pipelined kernel's edge intervals (first / last tiles of a row, rows of different workgroups, 1-step tails).
+Usage: python tools/hm_fuzz.py [n_cases]"""
+import os, sys, random, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from evo_amd.ops import default_ops
+from evo_amd.hyena_tables import mfma_operand_table, group_permutation
+from test_gpu_kernels import hyena_params, gen, bf
+ops = default_ops(); DEV = "cuda:0"
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rnd = random.Random(7)
+bad_cases = 0
+for case in range(n):
+    D, H = rnd.choice([(128, 1), (256, 2), (512, 4), (1024, 8)])
+    B = rnd.choice([1, 1, 2, 3, 5, 9, 33, 70]) if D <= 256 else rnd.choice([1, 2, 3, 5])
+    T = rnd.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 511, 512, 513, 514, 575, 576, 577, 1023, 1024, 1025, 1500, 2049, rnd.randint(1, 3000)])
+    if B * T * D > 3.0e7:
+        T = max(1, int(3.0e7 / (B * D)))
+    use_halo = rnd.random() < 0.4
+    prm = hyena_params(D, 100 + case); fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(200 + case))).to(DEV)
+    halo = bf(torch.randn(B, 2, 3 * D, generator=gen(300 + case))).to(DEV) if use_halo else None
+    tab = mfma_operand_table(poles, res, dskip)
+    perm = group_permutation(D, H, DEV)
+    ref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, z_halo=halo)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    y = ops.hyena_mfma_prefill(z[..., perm].contiguous(), fir_w, fir_b, dskip, tab, H, None if halo is None else halo[..., perm].contiguous())
+    y2 = ops.hyena_mfma_prefill(z[..., perm].contiguous(), fir_w, fir_b, dskip, tab, H, None if halo is None else halo[..., perm].contiguous())
+    torch.cuda.synchronize()
+    e = (y.double() - ref.double()).abs()
+    tol = ref.double().abs() * 2 ** -7 + float(ref.abs().max()) * 4e-3
+    nbad = int((e > tol).sum())
+    same = bool(torch.equal(y, y2))
+    if nbad or not same:
+        bad_cases += 1
+        print(f"case {case}: B={B} T={T} D={D} halo={use_halo}: bad={nbad} first={(e > tol).nonzero()[:2].tolist()} reproducible={same}")
+print(f"RESULT {n - bad_cases}/{n} cases agree")
