@@ -49,6 +49,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
         int64_t n = n0 + r < N ? n0 + r : N - 1;            // rows past the end are computed on a clamp, not stored
         wrow[r] = w + n * nvec;
     }
+    // the storing lane requests its bias / residual values NOW: fetched after the reduction they were a dependent ~1 us tail on
+    // a launch whose whole stream is 5-17 us (out_filter_dense, out_proj, l3)
+    const bool ep_lane = lane == 0 && (!SPLIT || wave == 0);
+    uint16_t pf_b[R], pf_r[R][M];
+    if (ep_lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t n = n0 + r < N ? n0 + r : N - 1;
+            pf_b[r] = bias ? bias[n] : (uint16_t)0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) pf_r[r][m] = res ? res[(int64_t)m * N + n] : (uint16_t)0;
+        }
+    }
     float acc[R][M];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -103,11 +116,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
         for (int r = 0; r < R; ++r) {
             const int64_t n = n0 + r;
             if (n < N) {
-                const float b = bias ? bf_to_f(bias[n]) : 0.f;
+                const float b = bias ? bf_to_f(pf_b[r]) : 0.f;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     float o = acc[r][m] + b;
-                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
+                    if (res) o += bf_to_f(pf_r[r][m]);
                     y[(int64_t)m * N + n] = f_to_bf(o);
                 }
             }
@@ -487,6 +500,18 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restric
     const int s0 = (int)((int64_t)nsteps * wave / 8), s1 = (int)((int64_t)nsteps * (wave + 1) / 8);
     const uint4* wp = w + (int64_t)nrow * nvec + kb;
     const uint4* xp = x + (int64_t)mrow * nvec + kb;
+    // wave 0 stores: its bias / residual values are requested ahead of the stream (see gemv_kernel)
+    uint16_t pf_b[4] = {0, 0, 0, 0}, pf_r[4] = {0, 0, 0, 0};
+    if (wave == 0 && r16 < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * kb + r;
+            if (n < N) {
+                if (bias) pf_b[r] = bias[n];
+                if (res) pf_r[r] = res[(int64_t)r16 * N + n];
+            }
+        }
+    }
     gv_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int s = s0;
     for (; s + 8 <= s1; s += 8) {
@@ -514,8 +539,8 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restric
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 4 * kb + r;
                 if (n < N) {
-                    float o = acc[r] + (bias ? bf_to_f(bias[n]) : 0.f);
-                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
+                    float o = acc[r] + (bias ? bf_to_f(pf_b[r]) : 0.f);
+                    if (res) o += bf_to_f(pf_r[r]);
                     y[(int64_t)m * N + n] = f_to_bf(o);
                 }
             }
