@@ -231,26 +231,26 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
 }
 
 // ---- the whole Hyena mixer input of a decode step in one launch: pre-norm + projection + FIR/modal step + gate.
-// A wave owns TWO adjacent channels (c, c+1) of one head = six rows of the projection weight (x2, x1, v thirds), streams
-// them like gemv_norm_kernel, and then its first 2 M lanes (one per channel x batch row) run evo_hyena_step's arithmetic
-// on the six dot products -- same operations in the same order, so outputs and carried states are bit-identical to
+// A wave owns CPW (one or two) adjacent channels of one head = 3 CPW rows of the projection weight (x2, x1, v thirds), streams
+// them like gemv_norm_kernel, and then its first CPW * M lanes (one per channel x batch row) run evo_hyena_step's arithmetic
+// on the dot products -- same operations in the same order, so outputs and carried states are bit-identical to
 // evo_norm_linear_small_m_bf16 followed by evo_hyena_step.
-template <int M>
+template <int M, int CPW>
 __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ scale, const uint4* __restrict__ w,
     const uint16_t* __restrict__ bias, uint16_t* __restrict__ fir_state, float* __restrict__ iir_state,
     const uint16_t* __restrict__ fir_w, const uint16_t* __restrict__ fir_b, const float* __restrict__ poles,
     const float* __restrict__ residues, const uint16_t* __restrict__ dskip, uint16_t* __restrict__ y, int D, int nvec,
     float eps, float inv_sqrt_d) {
-    constexpr int HDc = 128, NSc = 8, GV_R = 6;
+    constexpr int HDc = 128, NSc = 8, GV_R = 3 * CPW;      // CPW channels per wave (1 or 2)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x * 4 + wave;                     // channel pair index over D / 2
-    if (pair >= D / 2) return;
-    const int h = pair / (HDc / 2), j0 = 2 * (pair - h * (HDc / 2));
-    const uint4* wrow[6];
+    const int unit = blockIdx.x * 4 + wave;                     // channel (pair) index over D / CPW
+    if (unit >= D / CPW) return;
+    const int h = unit / (HDc / CPW), j0 = CPW * (unit - h * (HDc / CPW));
+    const uint4* wrow[GV_R];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r >> 1) * HDc + j0 + (r & 1)) * nvec;
+    for (int r = 0; r < GV_R; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r / CPW) * HDc + j0 + (r % CPW)) * nvec;
     // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
     // once instead of after a ~1.5 us reduction, and every later trip's loads are issued ahead of the trip that consumes
     // the previous ones (same arithmetic in the same order: results are bit-identical to the single-buffered loop)
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     // the epilogue's operands (this lane's channel x batch row: FIR taps / state / bias of x2, x1, v, the 8 poles, residues and
     // modal states, D) are requested NOW, behind the first weight trip: they do not depend on the dot products, and fetched
     // at the end they were a ~2 us dependent-latency tail per wave with nothing left to overlap it
-    const bool ep_lane = lane < 2 * M;
-    const int ep_e = lane & 1, ep_m = ep_lane ? lane >> 1 : 0;
+    const bool ep_lane = lane < CPW * M;
+    const int ep_e = lane % CPW, ep_m = ep_lane ? lane / CPW : 0;
     const int ep_dch = h * HDc + j0 + ep_e;
     uint16_t pf_bias[3], pf_fw[3][3], pf_fb[3], pf_fs[3][2], pf_dk = 0;
     float2 pf_p[NSc], pf_r[NSc], pf_s[NSc];
@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
         o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
         return o;
     };
-    float acc[6][M];
+    float acc[GV_R][M];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < GV_R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     int v = lane;
@@ -332,18 +332,18 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
         }
     }
     for (; v < nvec; v += 64) {
-        uint4 w0[6];
+        uint4 w0[GV_R];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) w0[r] = ld_stream(wrow[r] + v);
+        for (int r = 0; r < GV_R; ++r) w0[r] = ld_stream(wrow[r] + v);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const uint4 x0 = normed(m, v);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < GV_R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
     if (!ep_lane) return;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 #pragma unroll
         for (int mm = 0; mm < M; ++mm)
 #pragma unroll
-            for (int ee = 0; ee < 2; ++ee) d = (m == mm && e == ee) ? acc[2 * g + ee][mm] : d;
+            for (int ee = 0; ee < CPW; ++ee) d = (m == mm && e == ee) ? acc[CPW * g + ee][mm] : d;
         const int c = h * 3 * HDc + g * HDc + j0 + e;            // channel in the 3D row
         const uint16_t zraw = f_to_bf(d + bf_to_f(pf_bias[g]));  // what the unfused projection stores
         uint16_t* fs = fir_state + ((int64_t)m * 3 * D + c) * 2;
@@ -597,18 +597,21 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
                                               int64_t M, int64_t D, int64_t n_heads, float eps, void* stream) {
     if (M < 1 || M > 4 || D <= 0 || D != n_heads * 128 || D % 8 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((D / 2 + 3) / 4)), block(256);
+    // channels per wave, measured under a hipGraph on MI355X (tools/experiments/hyena_decode_cpw_bench.py): one channel per wave
+    // (twice the waves, half the bytes in flight each) is 5 % faster at M = 1 and 6 % at M = 4, two channels win at M = 2
+    // (22.8 / 26.1 / 42.6 us with two, 21.6 / 29.9 / 40.0 us with one, M = 1 / 2 / 4).  Same arithmetic either way.
     const float isd = 1.0f / sqrtf((float)D);
-#define EVO_HD(MM)                                                                                            \
-    hipLaunchKernelGGL((gemv_norm_hyena_kernel<MM>), grid, block, 0, s, (const uint4*)x, (const uint4*)norm_scale, \
+#define EVO_HD(MM, CPW)                                                                                       \
+    hipLaunchKernelGGL((gemv_norm_hyena_kernel<MM, CPW>), dim3((unsigned)((D / CPW + 3) / 4)), dim3(256), 0, s, \
+                       (const uint4*)x, (const uint4*)norm_scale,                                             \
                        (const uint4*)proj_w, (const uint16_t*)proj_b, (uint16_t*)fir_state, iir_state,          \
                        (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, residues, (const uint16_t*)dskip, \
                        (uint16_t*)y, (int)D, (int)(D / 8), eps, isd)
     switch (M) {
-        case 1: EVO_HD(1); break;
-        case 2: EVO_HD(2); break;
-        case 3: EVO_HD(3); break;
-        default: EVO_HD(4); break;
+        case 1: EVO_HD(1, 1); break;
+        case 2: EVO_HD(2, 2); break;
+        case 3: EVO_HD(3, 2); break;
+        default: EVO_HD(4, 1); break;
     }
 #undef EVO_HD
     return evo_launch_status();
