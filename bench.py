@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-gen", action="store_true")
     ap.add_argument("--steps-131k", type=int, default=2)
+    ap.add_argument("--sp-timeout", type=float, default=420.0, help="N > 1: seconds the sequence-parallel 131k leg may take")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -339,10 +340,34 @@ def main():
 
     # ------------------------------------------------------------------ secondary: 131,072-nt context
     if not args.skip_131k:
+        # N > 1: the sequence-parallel leg is the only part of this script with data-path collectives.  A rank that fails
+        # inside it would leave the others waiting in RCCL until the collective timeout, and the headline line (measured above)
+        # would never be printed: a watchdog prints what has been measured and ends every rank instead.
+        watchdog = None
+        if dist_on:
+            import threading
+
+            def _bail():
+                if rank == 0:
+                    out["ctx131k"] = {"error": f"sequence-parallel leg did not finish within {args.sp_timeout} s; abandoned"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.sp_timeout, _bail)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             out["ctx131k"] = bench_131k(args, device, rank, world, dist_on, ops)
         except Exception as e:  # noqa: BLE001  (report, never hide)
             out["ctx131k"] = {"error": f"{type(e).__name__}: {e}"}
+            if dist_on:                                   # the other ranks may be inside a collective this rank left
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                    os._exit(0)
+                os._exit(0)
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
 
     # ------------------------------------------------------------------ generation (BASELINE configs[4]), N = 1 only
     if n_gpus == 1 and not args.skip_gen:
