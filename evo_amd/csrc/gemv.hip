@@ -128,11 +128,92 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     }
 }
 
+// STAGE: wave m of the workgroup (m < M <= 4) normalises batch row m ONCE into LDS and every wave's trips read it from there.
+// Two things were wrong with every wave rebuilding the normalised slices itself: the sum of squares was a loop of one 16-byte
+// load + s_waitcnt vmcnt(0) per 64-vector slice -- eight dependent L2 round trips per row, queued BEHIND the weight prefetch
+// (vmcnt retires in order), ~6 us of every wave's life at M = 1 -- and at M >= 2 the per-trip re-normalisation made the
+// launches VALU-bound (fused Hyena step 22 / 26 / 43 us at M = 1 / 2 / 4 against 20-22 us for the plain GEMV of the matrix).
+// Here the staging wave requests its row's 2 x 8 vectors at once, AHEAD of its weight prefetch, reduces in rmsnorm_kernel's
+// order (lane-strided sequential fp32, wave butterfly) and stores the normalised row: bit-identical values, one L2 round trip.
+#define GV_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // orders LDS only: weight loads stay in flight
+extern __shared__ uint4 gv_xn[];                                                          // [M][nvec] normalised rows (STAGE)
+
+__device__ __forceinline__ uint4 gv_norm8(const uint4& xv, const uint4& sv, float inv) {
+    uint4 o;
+    o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv), bf_hi(sv.x) * (bf_hi(xv.x) * inv));
+    o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv), bf_hi(sv.y) * (bf_hi(xv.y) * inv));
+    o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv), bf_hi(sv.z) * (bf_hi(xv.z) * inv));
+    o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv), bf_hi(sv.w) * (bf_hi(xv.w) * inv));
+    return o;
+}
+__device__ __forceinline__ float gv_sumsq8(const uint4& xv, float ss) {
+    const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+    return ss;
+}
+// rows of up to 512 vectors (K <= 4096; longer rows take the unstaged kernels): request everything (slices past the row end
+// re-read the lane's first vector, unused)
+__device__ __forceinline__ void gv_stage_load(const uint4* xr, const uint4* scale, int nvec, int lane, uint4 (&sx)[8], uint4 (&sc)[8]) {
+    const int v0 = lane < nvec ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = lane + 64 * i, vc = v < nvec ? v : v0;
+        sx[i] = xr[vc];
+        sc[i] = scale[vc];
+    }
+}
+__device__ __forceinline__ void gv_stage_finish(uint4* dst, int nvec, int lane, float eps, float inv_sqrt_d, const uint4 (&sx)[8],
+                                                const uint4 (&sc)[8]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nvec) ss = gv_sumsq8(sx[i], ss);
+    ss = wave_sum(ss);
+    const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+    uint4 px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                            // (opaque copy: otherwise the 64 unpacked fp32 values of the reduction are
+        px[i] = sx[i];                                       //  kept alive across it for the normalisation, +64 VGPRs on every wave)
+        asm volatile("" : "+v"(px[i].x), "+v"(px[i].y), "+v"(px[i].z), "+v"(px[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nvec) dst[lane + 64 * i] = gv_norm8(px[i], sc[i], inv);
+}
+// K = 4096 (nvec = 512: every decode layer behind a norm) written out as four trips with a two-deep register pipeline: the
+// generic loop below ends each trip by copying the next trip's registers over the current ones, which makes the compiler wait
+// for the loads it has just issued -- one trip in flight per wave.  Same operations in the same order.
+#define GV_TRIP_LOAD(BUF, T)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < GV_R; ++r) {                                                                \
+        BUF[r] = ld_stream(wrow[r] + lane + 128 * (T));                                                               \
+        BUF[GV_R + r] = ld_stream(wrow[r] + lane + 128 * (T) + 64);                                                   \
+    }
+#define GV_TRIP_DOT(BUF, T, XF)                                                                                       \
+    _Pragma("unroll") for (int m = 0; m < M; ++m) {                                                                   \
+        const uint4 x0 = XF(m, lane + 128 * (T)), x1 = XF(m, lane + 128 * (T) + 64);                                  \
+        _Pragma("unroll") for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(BUF[GV_R + r], x1, dot8(BUF[r], x0, acc[r][m])); \
+    }
+#define GV_FOUR_TRIPS(XF)                                                                                             \
+    {                                                                                                                 \
+        uint4 wb[2 * GV_R];                                                                                           \
+        GV_TRIP_LOAD(wb, 1)                                                                                           \
+        GV_TRIP_DOT(wa, 0, XF)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0); /* (keeps the LDS reads of later trips from being hoisted: 32 M VGPRs) */  \
+        GV_TRIP_LOAD(wa, 2)                                                                                           \
+        GV_TRIP_DOT(wb, 1, XF)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        GV_TRIP_LOAD(wb, 3)                                                                                           \
+        GV_TRIP_DOT(wa, 2, XF)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        GV_TRIP_DOT(wb, 3, XF)                                                                                        \
+    }
+
 // ---- RMSNorm folded into the layer that consumes it (decode form): y = bf16(scale * x / (rms(x) + eps)) . W^T + bias.
 // Every wave first reduces sum(x^2) with the rmsnorm kernel's own lane -> element mapping and summation order (so the
 // normalised row is bit-identical to what that kernel would have stored), then streams its R rows of W while it
 // rebuilds the normalised x slice by slice in registers -- one launch instead of two per block.
-template <int M, int R>
+template <int M, int R, bool STAGE>
 __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
                                                         const uint4* __restrict__ w, const uint16_t* __restrict__ bias,
                                                         uint16_t* __restrict__ y, int N, int nvec, float eps, float inv_sqrt_d) {
@@ -140,13 +221,18 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * R;
-    if (n0 >= N) return;
+    if (!STAGE && n0 >= N) return;                           // (STAGE: every wave helps to stage x, then leaves)
     const uint4* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int64_t n = n0 + r < N ? n0 + r : N - 1;
         wrow[r] = w + n * nvec;
     }
+    // (STAGE) the staging wave's x / scale requests go out first, so they come back first
+    uint4 st_x[8], st_s[8];
+    const bool stager = STAGE && wave < M;
+    if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
+    __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
     // once instead of after a ~1.5 us reduction, and every later trip's loads are issued ahead of the trip that consumes
     // the previous ones (same arithmetic in the same order: results are bit-identical to the single-buffered loop)
@@ -158,18 +244,17 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     }
     float inv[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        float ss = 0.f;
-        for (int v = lane; v < nvec; v += 64) {
-            const uint4 xv = x[(int64_t)m * nvec + v];
-            const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+    for (int m = 0; m < M; ++m) inv[m] = 0.f;
+    if (!STAGE) {                                            // rows too long for LDS: every wave reduces every row itself
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        for (int m = 0; m < M; ++m) {
+            float ss = 0.f;
+            for (int v = lane; v < nvec; v += 64) ss = gv_sumsq8(x[(int64_t)m * nvec + v], ss);
+            ss = wave_sum(ss);
+            inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
         }
-        ss = wave_sum(ss);
-        inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
     }
-    auto normed = [&](int m, int v) {
+    auto normed_calc = [&](int m, int v) {
         const uint4 xv = x[(int64_t)m * nvec + v], sv = scale[v];
         uint4 o;
         o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
@@ -178,39 +263,50 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
         o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
         return o;
     };
+    if (STAGE) {
+        if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        GV_WG_BARRIER();
+        if (n0 >= N) return;
+        __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
+    }
+    auto normed = [&](int m, int v) { return STAGE ? gv_xn[m * nvec + v] : normed_calc(m, v); };
     float acc[R][M];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-    int v = lane;
-    for (; v + 64 < nvec; v += 128) {
-        uint4 wb[2 * GV_R];
-        const bool more = v + 128 + 64 < nvec;
-        if (more) {
+    if constexpr (STAGE) {                                   // (STAGE launches have nvec == 512: the host checks)
+        GV_FOUR_TRIPS(normed)
+    } else {
+        int v = lane;
+        for (; v + 64 < nvec; v += 128) {
+            uint4 wb[2 * GV_R];
+            const bool more = v + 128 + 64 < nvec;
+            if (more) {
 #pragma unroll
-            for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+                for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+#pragma unroll
+                for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
+            }
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
+            }
         }
+        for (; v < nvec; v += 64) {
+            uint4 w0[R];
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+            for (int r = 0; r < R; ++r) w0[r] = ld_stream(wrow[r] + v);
 #pragma unroll
-            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
-        }
-        if (more) {
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = normed(m, v);
 #pragma unroll
-            for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
-        }
-    }
-    for (; v < nvec; v += 64) {
-        uint4 w0[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) w0[r] = ld_stream(wrow[r] + v);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = normed(m, v);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+                for (int r = 0; r < R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+            }
         }
     }
 #pragma unroll
@@ -235,7 +331,7 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
 // them like gemv_norm_kernel, and then its first CPW * M lanes (one per channel x batch row) run evo_hyena_step's arithmetic
 // on the dot products -- same operations in the same order, so outputs and carried states are bit-identical to
 // evo_norm_linear_small_m_bf16 followed by evo_hyena_step.
-template <int M, int CPW>
+template <int M, int CPW, bool STAGE>
 __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ scale, const uint4* __restrict__ w,
     const uint16_t* __restrict__ bias, uint16_t* __restrict__ fir_state, float* __restrict__ iir_state,
@@ -246,11 +342,17 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int unit = blockIdx.x * 4 + wave;                     // channel (pair) index over D / CPW
-    if (unit >= D / CPW) return;
-    const int h = unit / (HDc / CPW), j0 = CPW * (unit - h * (HDc / CPW));
+    if (!STAGE && unit >= D / CPW) return;
+    const int unit_c = unit < D / CPW ? unit : D / CPW - 1;      // (STAGE: a wave past the end stages x with the others, then leaves)
+    const int h = unit_c / (HDc / CPW), j0 = CPW * (unit_c - h * (HDc / CPW));
     const uint4* wrow[GV_R];
 #pragma unroll
     for (int r = 0; r < GV_R; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r / CPW) * HDc + j0 + (r % CPW)) * nvec;
+    // (STAGE) the staging wave's x / scale requests go out first, so they come back first
+    uint4 st_x[8], st_s[8];
+    const bool stager = STAGE && wave < M;
+    if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
+    __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
     // once instead of after a ~1.5 us reduction, and every later trip's loads are issued ahead of the trip that consumes
     // the previous ones (same arithmetic in the same order: results are bit-identical to the single-buffered loop)
@@ -260,8 +362,35 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 #pragma unroll
         for (int r = 0; r < GV_R; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[GV_R + r] = ld_stream(wrow[r] + lane + 64); }
     }
+    float inv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) inv[m] = 0.f;
+    if (!STAGE) {                                            // rows too long for LDS: every wave reduces every row itself
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float ss = 0.f;
+            for (int v = lane; v < nvec; v += 64) ss = gv_sumsq8(x[(int64_t)m * nvec + v], ss);
+            ss = wave_sum(ss);
+            inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
+        }
+    }
+    auto normed_calc = [&](int m, int v) {
+        const uint4 xv = x[(int64_t)m * nvec + v], sv = scale[v];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
+        o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv[m]), bf_hi(sv.y) * (bf_hi(xv.y) * inv[m]));
+        o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv[m]), bf_hi(sv.z) * (bf_hi(xv.z) * inv[m]));
+        o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
+        return o;
+    };
+    if (STAGE) {
+        if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        GV_WG_BARRIER();
+        if (unit >= D / CPW) return;
+        __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
+    }
     // the epilogue's operands (this lane's channel x batch row: FIR taps / state / bias of x2, x1, v, the 8 poles, residues and
-    // modal states, D) are requested NOW, behind the first weight trip: they do not depend on the dot products, and fetched
+    // modal states, D) are requested NOW (after the staging, whose registers they reuse), behind the first weight trip: they do not depend on the dot products, and fetched
     // at the end they were a ~2 us dependent-latency tail per wave with nothing left to overlap it
     const bool ep_lane = lane < CPW * M;
     const int ep_e = lane % CPW, ep_m = ep_lane ? lane / CPW : 0;
@@ -285,61 +414,44 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
         for (int sI = 0; sI < NSc; ++sI) { pf_p[sI] = pp[sI]; pf_r[sI] = rp[sI]; pf_s[sI] = st[sI]; }
         pf_dk = dskip[ep_dch];
     }
-    float inv[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        float ss = 0.f;
-        for (int v = lane; v < nvec; v += 64) {
-            const uint4 xv = x[(int64_t)m * nvec + v];
-            const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
-        }
-        ss = wave_sum(ss);
-        inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
-    }
-    auto normed = [&](int m, int v) {
-        const uint4 xv = x[(int64_t)m * nvec + v], sv = scale[v];
-        uint4 o;
-        o.x = pack_bf2(bf_lo(sv.x) * (bf_lo(xv.x) * inv[m]), bf_hi(sv.x) * (bf_hi(xv.x) * inv[m]));
-        o.y = pack_bf2(bf_lo(sv.y) * (bf_lo(xv.y) * inv[m]), bf_hi(sv.y) * (bf_hi(xv.y) * inv[m]));
-        o.z = pack_bf2(bf_lo(sv.z) * (bf_lo(xv.z) * inv[m]), bf_hi(sv.z) * (bf_hi(xv.z) * inv[m]));
-        o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
-        return o;
-    };
+    auto normed = [&](int m, int v) { return STAGE ? gv_xn[m * nvec + v] : normed_calc(m, v); };
     float acc[GV_R][M];
 #pragma unroll
     for (int r = 0; r < GV_R; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-    int v = lane;
-    for (; v + 64 < nvec; v += 128) {
-        uint4 wb[2 * GV_R];
-        const bool more = v + 128 + 64 < nvec;
-        if (more) {
+    if constexpr (STAGE) {                                   // (STAGE launches have nvec == 512: the host checks)
+        GV_FOUR_TRIPS(normed)
+    } else {
+        int v = lane;
+        for (; v + 64 < nvec; v += 128) {
+            uint4 wb[2 * GV_R];
+            const bool more = v + 128 + 64 < nvec;
+            if (more) {
 #pragma unroll
-            for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+                for (int r = 0; r < GV_R; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[GV_R + r] = ld_stream(wrow[r] + v + 192); }
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+#pragma unroll
+                for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
+            }
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
+            }
         }
+        for (; v < nvec; v += 64) {
+            uint4 w0[GV_R];
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = normed(m, v), x1 = normed(m, v + 64);
+            for (int r = 0; r < GV_R; ++r) w0[r] = ld_stream(wrow[r] + v);
 #pragma unroll
-            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(wa[GV_R + r], x1, dot8(wa[r], x0, acc[r][m]));
-        }
-        if (more) {
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = normed(m, v);
 #pragma unroll
-            for (int r = 0; r < 2 * GV_R; ++r) wa[r] = wb[r];
-        }
-    }
-    for (; v < nvec; v += 64) {
-        uint4 w0[GV_R];
-#pragma unroll
-        for (int r = 0; r < GV_R; ++r) w0[r] = ld_stream(wrow[r] + v);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = normed(m, v);
-#pragma unroll
-            for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+                for (int r = 0; r < GV_R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+            }
         }
     }
 #pragma unroll
@@ -384,20 +496,26 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 // streaming loop as gemv_kernel; a wave owns 2 output columns = rows (n, n+1) of W1 and (I+n, I+n+1) of W2, rounds both
 // dot products to bf16 (what the unfused GEMM stores) and applies the gate -- one launch instead of two per block.
 // NORM: x is the un-normalised residual row and `scale` the RMSNorm weight (same fold as gemv_norm_kernel).
-template <int M, bool NORM>
+template <int M, bool NORM, bool STAGE>
 __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
                                                         const uint4* __restrict__ w, uint16_t* __restrict__ a, int I,
                                                         int nvec, float eps, float inv_sqrt_d) {
+    constexpr int GV_R = 4;                                  // rows per wave: (n, n+1) of W1 and of W2
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
-    if (n0 >= I) return;
+    if (!STAGE && n0 >= I) return;
     const uint4* wrow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int64_t n = n0 + (r & 1) < I ? n0 + (r & 1) : I - 1;
         wrow[r] = w + ((r >> 1) * (int64_t)I + n) * nvec;
     }
+    // (STAGE) the staging wave's x / scale requests go out first, so they come back first
+    uint4 st_x[8], st_s[8];
+    const bool stager = STAGE && wave < M;
+    if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
+    __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // first trip's weights before the norm pass, every later trip one ahead (see gemv_norm_kernel)
     uint4 wa[8];
     if (lane + 64 < nvec) {
@@ -405,21 +523,18 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         for (int r = 0; r < 4; ++r) { wa[r] = ld_stream(wrow[r] + lane); wa[4 + r] = ld_stream(wrow[r] + lane + 64); }
     }
     float inv[M];
-    if (NORM) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) inv[m] = 0.f;
+    if (NORM && !STAGE) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float ss = 0.f;
-            for (int v = lane; v < nvec; v += 64) {
-                const uint4 xv = x[(int64_t)m * nvec + v];
-                const float f[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
-            }
+            for (int v = lane; v < nvec; v += 64) ss = gv_sumsq8(x[(int64_t)m * nvec + v], ss);
             ss = wave_sum(ss);
             inv[m] = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
         }
     }
-    auto xin = [&](int m, int v) {
+    auto xin_calc = [&](int m, int v) {
         const uint4 xv = x[(int64_t)m * nvec + v];
         if (!NORM) return xv;
         const uint4 sv = scale[v];
@@ -430,39 +545,50 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
         o.w = pack_bf2(bf_lo(sv.w) * (bf_lo(xv.w) * inv[m]), bf_hi(sv.w) * (bf_hi(xv.w) * inv[m]));
         return o;
     };
+    if (STAGE) {
+        if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        GV_WG_BARRIER();
+        if (n0 >= I) return;
+        __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
+    }
+    auto xin = [&](int m, int v) { return STAGE ? gv_xn[m * nvec + v] : xin_calc(m, v); };
     float acc[4][M];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-    int v = lane;
-    for (; v + 64 < nvec; v += 128) {
-        uint4 wb[8];
-        const bool more = v + 128 + 64 < nvec;
-        if (more) {
+    if constexpr (STAGE) {                                   // (STAGE launches have nvec == 512: the host checks)
+        GV_FOUR_TRIPS(xin)
+    } else {
+        int v = lane;
+        for (; v + 64 < nvec; v += 128) {
+            uint4 wb[8];
+            const bool more = v + 128 + 64 < nvec;
+            if (more) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[4 + r] = ld_stream(wrow[r] + v + 192); }
+                for (int r = 0; r < 4; ++r) { wb[r] = ld_stream(wrow[r] + v + 128); wb[4 + r] = ld_stream(wrow[r] + v + 192); }
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = xin(m, v), x1 = xin(m, v + 64);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r][m] = dot8(wa[4 + r], x1, dot8(wa[r], x0, acc[r][m]));
+            }
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) wa[r] = wb[r];
+            }
         }
+        for (; v < nvec; v += 64) {
+            uint4 w0[4];
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = xin(m, v), x1 = xin(m, v + 64);
+            for (int r = 0; r < 4; ++r) w0[r] = ld_stream(wrow[r] + v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(wa[4 + r], x1, dot8(wa[r], x0, acc[r][m]));
-        }
-        if (more) {
+            for (int m = 0; m < M; ++m) {
+                const uint4 x0 = xin(m, v);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) wa[r] = wb[r];
-        }
-    }
-    for (; v < nvec; v += 64) {
-        uint4 w0[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w0[r] = ld_stream(wrow[r] + v);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint4 x0 = xin(m, v);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+                for (int r = 0; r < 4; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+            }
         }
     }
 #pragma unroll
@@ -578,9 +704,15 @@ extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, co
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(((N + 3) / 4 + 3) / 4)), block(256);
     const float isd = 1.0f / sqrtf((float)K);
+    const size_t lds = (size_t)M * K * 2;                   // normalised rows staged in LDS (when they fit)
+    const bool stage = K == 4096;                            // the staged kernels are written out for four 1024-element trips
 #define EVO_NL(MM)                                                                                            \
-    hipLaunchKernelGGL((gemv_norm_kernel<MM, 4>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale,    \
-                       (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd)
+    if (stage)                                                                                                \
+        hipLaunchKernelGGL((gemv_norm_kernel<MM, 4, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
+                           (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd); \
+    else                                                                                                      \
+        hipLaunchKernelGGL((gemv_norm_kernel<MM, 4, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
+                           (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd)
     switch (M) {
         case 1: EVO_NL(1); break;
         case 2: EVO_NL(2); break;
@@ -600,18 +732,26 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
     // channels per wave, measured under a hipGraph on MI355X (tools/experiments/hyena_decode_cpw_bench.py): one channel per wave
     // (twice the waves, half the bytes in flight each) is 5 % faster at M = 1 and 6 % at M = 4, two channels win at M = 2
     // (22.8 / 26.1 / 42.6 us with two, 21.6 / 29.9 / 40.0 us with one, M = 1 / 2 / 4).  Same arithmetic either way.
+#ifndef GEMV_HYENA_CPW_STAGED
+#define GEMV_HYENA_CPW_STAGED 1
+#endif
+#ifndef GEMV_HYENA_CPW_STAGED1
+#define GEMV_HYENA_CPW_STAGED1 1
+#endif
     const float isd = 1.0f / sqrtf((float)D);
-#define EVO_HD(MM, CPW)                                                                                       \
-    hipLaunchKernelGGL((gemv_norm_hyena_kernel<MM, CPW>), dim3((unsigned)((D / CPW + 3) / 4)), dim3(256), 0, s, \
+    const size_t lds = (size_t)M * D * 2;
+#define EVO_HD(MM, CPW, ST)                                                                                   \
+    hipLaunchKernelGGL((gemv_norm_hyena_kernel<MM, CPW, ST>), dim3((unsigned)((D / CPW + 3) / 4)), dim3(256), ST ? lds : 0, s, \
                        (const uint4*)x, (const uint4*)norm_scale,                                             \
                        (const uint4*)proj_w, (const uint16_t*)proj_b, (uint16_t*)fir_state, iir_state,          \
                        (const uint16_t*)fir_w, (const uint16_t*)fir_b, poles, residues, (const uint16_t*)dskip, \
                        (uint16_t*)y, (int)D, (int)(D / 8), eps, isd)
+    const bool stage = D == 4096;
     switch (M) {
-        case 1: EVO_HD(1, 1); break;
-        case 2: EVO_HD(2, 2); break;
-        case 3: EVO_HD(3, 2); break;
-        default: EVO_HD(4, 1); break;
+        case 1: if (stage) EVO_HD(1, GEMV_HYENA_CPW_STAGED1, true); else EVO_HD(1, 1, false); break;
+        case 2: if (stage) EVO_HD(2, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(2, 2, false); break;
+        case 3: if (stage) EVO_HD(3, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(3, 2, false); break;
+        default: if (stage) EVO_HD(4, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(4, 1, false); break;
     }
 #undef EVO_HD
     return evo_launch_status();
@@ -622,12 +762,17 @@ static int mlp_gate_launch(const void* x, const void* scale, const void* w12, vo
     if (M < 1 || M > 4 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
     const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
     const float isd = 1.0f / sqrtf((float)K);
+    const size_t lds = (size_t)M * K * 2;
+    const bool stage = scale && K == 4096;
 #define EVO_MG(MM)                                                                                            \
-    if (scale)                                                                                                \
-        hipLaunchKernelGGL((gemv_gate_kernel<MM, true>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
+    if (scale && stage)                                                                                       \
+        hipLaunchKernelGGL((gemv_gate_kernel<MM, true, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd);                  \
+    else if (scale)                                                                                           \
+        hipLaunchKernelGGL((gemv_gate_kernel<MM, true, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
                            (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd);                  \
     else                                                                                                      \
-        hipLaunchKernelGGL((gemv_gate_kernel<MM, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)nullptr, \
+        hipLaunchKernelGGL((gemv_gate_kernel<MM, false, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)nullptr, \
                            (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), 0.f, 0.f)
     switch (M) {
         case 1: EVO_MG(1); break;
