@@ -32,14 +32,21 @@ for M in (1, 2, 3, 4):
                          poles=torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous(),
                          res=rn(D, 8, 2, std=.25).float().contiguous(), dk=rn(D, std=.5).bfloat16(), fs=rn(M, 3 * D, 2).bfloat16(),
                          iir=torch.view_as_complex(rn(M, D, 8, 2, std=.5).float().contiguous()),
-                         w12=rn(2 * I, D, std=.02).bfloat16()))
+                         w12=rn(2 * I, D, std=.02).bfloat16(), wo=rn(D, D, std=.02).bfloat16(), bo=rn(D, std=.1).bfloat16(),
+                         w3=rn(D, I, std=.02).bfloat16()))
+    a_in = rn(M, I).bfloat16(); y_in = rn(M, D).bfloat16(); xr = rn(M, D).bfloat16(); xr0 = xr.clone()
     hy = lambda b: ops.hyena_decode_fused(x, b["pre"], 1e-6, b["wp"], b["bp"], b["fs"], b["iir"], b["fw"], b["fb"], b["poles"], b["res"], b["dk"], H)
     gt = lambda b: ops.mlp_gate(x, b["w12"], b["pre"], 1e-6)
     nl = lambda b: ops.norm_linear(x, b["pre"], 1e-6, b["wp"], b["bp"])
+    ou = lambda b: ops.linear_residual_(xr, y_in, b["wo"], bias=b["bo"])
+    l3 = lambda b: ops.linear_residual_(xr, a_in, b["w3"])
+    t_ou = graph_time([lambda b=b: ou(b) for b in sets])
+    t_l3 = graph_time([lambda b=b: l3(b) for b in sets])
+    xr.copy_(xr0); ou(sets[0]); c_ou = float(xr.float().sum()); xr.copy_(xr0); l3(sets[0]); c_l3 = float(xr.float().sum())
     t_hy = graph_time([lambda b=b: hy(b) for b in sets])
     t_gt = graph_time([lambda b=b: gt(b) for b in sets])
     t_nl = graph_time([lambda b=b: nl(b) for b in sets])
     b = sets[0]
     c = (float(hy(b).float().sum()), float(b["iir"].abs().sum()), float(gt(b).float().sum()), float(nl(b).float().sum()))
     torch.cuda.synchronize()
-    print(f"[{tag}] M={M}: hyena {t_hy:.1f} us  norm+l1l2+gate {t_gt:.1f} us  norm+Wqkv {t_nl:.1f} us | checksums {c[0]:.4f} {c[1]:.2f} {c[2]:.4f} {c[3]:.3f}")
+    print(f"[{tag}] M={M}: hyena {t_hy:.1f} us  norm+l1l2+gate {t_gt:.1f} us  norm+Wqkv {t_nl:.1f} us  out {t_ou:.1f} us  l3 {t_l3:.1f} us | checksums {c_ou:.3f} {c_l3:.3f} {c[0]:.4f} {c[1]:.2f} {c[2]:.4f} {c[3]:.3f}")
