@@ -654,23 +654,160 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pipe_kernel(AttnArgs a) {
     }
 }
 
-// merge the splits of one (batch, head): out[d] = sum_s O_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M)
-__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+// ---- decode attention, streaming form.  One query row per (batch, head) makes this a bandwidth problem: the KV cache is read
+// once (4 * H * 128 bytes per key) and nothing is reused.  The MFMA kernel above (DECODE = true) moves every tile global ->
+// VGPR -> LDS -> fragments behind a workgroup barrier for ONE useful row of its 32-row tiles and tops out at 2.1-2.9 TB/s
+// (8 k ... 131 k keys).  Here a WAVE owns a run of 64-key blocks and there is no LDS and no barrier:
+//   lane = (ks = lane >> 4, dc = lane & 15): in step i of a block the lane holds the dc-th 16-byte chunk of key 4 i + ks, so
+//   every request covers four whole 256-byte rows; all 32 requests of a block (16 K, 16 V: 32 KiB per wave) go out together.
+//   score: 8-element partial dot with the lane's q chunk (v_dot2), summed over the 16 lanes of the key; softmax statistics are
+//   per block (online across blocks, log2 domain, fp32); P.V: each lane accumulates its 8 output dims over its keys, the four
+//   key groups meet at the end.  The split's unnormalised (O, m, l) goes to the same partial buffers as before.
+typedef __bf16 attn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float attn_dot8(const uint4& a, const uint4& b) {
+    float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a.x), __builtin_bit_cast(attn_bf16x2, b.x), 0.f, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a.y), __builtin_bit_cast(attn_bf16x2, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a.z), __builtin_bit_cast(attn_bf16x2, b.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a.w), __builtin_bit_cast(attn_bf16x2, b.w), acc, false);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void attn_decode_stream_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.y, bat = blockIdx.z;
+    const int split = blockIdx.x * 4 + wave;                 // one split of the key range per wave
+    int64_t n_keys = a.Tk;
+    if (a.dyn_pos) n_keys = a.dyn_pos[bat] + 1;              // the query at position p sees keys [0, p]
+    const int nblk = (int)((n_keys + 63) >> 6);              // split s takes blocks s, s + n_splits, ...: the waves resident at one
+                                                             // time read neighbouring blocks (contiguous runs per split put them
+                                                             // megabytes apart at equal offsets: 591 us instead of 429 at 131 k keys)
+    const int ks = lane >> 4, dc = lane & 15;
+    const uint4 qv = ((const uint4*)(a.q + bat * a.q_sb + head * a.q_sh))[dc];
+    const unsigned char* kp = (const unsigned char*)(a.k + bat * a.k_sb + head * a.k_sh) + dc * 16;
+    const unsigned char* vp = (const unsigned char*)(a.v + bat * a.v_sb + head * a.v_sh) + dc * 16;
+    const int64_t kst = a.k_st * 2, vst = a.v_st * 2;
+    float m_run = -INFINITY, l_run = 0.f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int blk = split; blk < nblk; blk += a.n_splits) {
+        const int64_t k0 = (int64_t)blk * 64 + ks;
+        uint4 kr[16], vr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int64_t key = k0 + 4 * i;
+            key = key < n_keys ? key : n_keys - 1;           // a ragged last block re-reads the last key (masked below)
+            kr[i] = *(const uint4*)(kp + key * kst);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int64_t key = k0 + 4 * i;
+            key = key < n_keys ? key : n_keys - 1;
+            vr[i] = *(const uint4*)(vp + key * vst);
+        }
+        float sc[16];
+        float mb = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float d = attn_dot8(kr[i], qv);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            d += __shfl_xor(d, 8, 64);
+            sc[i] = k0 + 4 * i < n_keys ? d * a.scale_log2 : -INFINITY;
+            mb = fmaxf(mb, sc[i]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_run, mb);                // finite: the block holds at least one key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pw = __builtin_amdgcn_exp2f(sc[i] - m_new);
+            l_run += pw;
+            o[0] = fmaf(pw, bf_lo(vr[i].x), o[0]); o[1] = fmaf(pw, bf_hi(vr[i].x), o[1]);
+            o[2] = fmaf(pw, bf_lo(vr[i].y), o[2]); o[3] = fmaf(pw, bf_hi(vr[i].y), o[3]);
+            o[4] = fmaf(pw, bf_lo(vr[i].z), o[4]); o[5] = fmaf(pw, bf_hi(vr[i].z), o[5]);
+            o[6] = fmaf(pw, bf_lo(vr[i].w), o[6]); o[7] = fmaf(pw, bf_hi(vr[i].w), o[7]);
+        }
+        m_run = m_new;
+    }
+    // the four key groups of the wave meet (every lane of a group carries the same l)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += __shfl_xor(o[e], 16, 64);
+        o[e] += __shfl_xor(o[e], 32, 64);
+    }
+    if (split < a.n_splits) {
+        const int64_t slot = ((int64_t)bat * a.H + head) * a.n_splits + split;
+        if (ks == 0) {
+            float4* po = (float4*)(a.part_o + slot * DH + dc * 8);
+            po[0] = make_float4(o[0], o[1], o[2], o[3]);
+            po[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (lane == 0) { a.part_ml[slot * 2] = m_run; a.part_ml[slot * 2 + 1] = l_run; }
+    }
+}
+
+// merge the splits of one (batch, head): out[d] = sum_s O_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M).
+// 512 threads = 4 groups x 128 output dims; the statistics are read once into LDS (coalesced) and turned into weights, then
+// group g sums splits g, g + 4, ... with eight independent row loads in flight (the first version walked the splits one
+// dependent L2 round trip at a time: 7 us at 16 splits, ~30 us at the 64 the streaming kernel uses).
+#define ATTN_MAX_SPLITS 1024
+__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
                                                                   uint16_t* __restrict__ o, int H, int n_splits) {
-    const int d = threadIdx.x, head = blockIdx.x, bat = blockIdx.y;
+    __shared__ float w_s[ATTN_MAX_SPLITS];
+    __shared__ float red[16];
+    __shared__ float acc_s[4][DH];
+    const int tid = threadIdx.x, d = tid & (DH - 1), g = tid >> 7, head = blockIdx.x, bat = blockIdx.y;
     const int64_t base = ((int64_t)bat * H + head) * n_splits;
+    // pass 1: maxima
     float M = -INFINITY;
-    for (int s = 0; s < n_splits; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
-    float L = 0.f, acc = 0.f;
-    for (int s = 0; s < n_splits; ++s) {
+    for (int s = tid; s < n_splits; s += 512) M = fmaxf(M, part_ml[(base + s) * 2]);
+    M = wave_max(M);
+    if ((tid & 63) == 0) red[tid >> 6] = M;
+    __syncthreads();
+    M = red[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) M = fmaxf(M, red[i]);
+    // pass 2: weights and denominator
+    float L = 0.f;
+    for (int s = tid; s < n_splits; s += 512) {
         const float m = part_ml[(base + s) * 2];
-        if (m == -INFINITY) continue;
-        const float w = __builtin_amdgcn_exp2f(m - M);
+        const float w = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - M);
+        w_s[s] = w;
         L = fmaf(part_ml[(base + s) * 2 + 1], w, L);
-        acc = fmaf(part_o[(base + s) * DH + d], w, acc);
     }
-    o[((int64_t)bat * H + head) * DH + d] = f_to_bf(L > 0.f ? acc / L : 0.f);
+    L = wave_sum(L);
+    if ((tid & 63) == 0) red[8 + (tid >> 6)] = L;
+    __syncthreads();
+    L = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) L += red[8 + i];
+    // pass 3: weighted rows
+    float acc = 0.f;
+    int s = g;
+    for (; s + 28 < n_splits; s += 32) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = part_o[(base + s + 4 * u) * DH + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(r[u], w_s[s + 4 * u], acc);
+    }
+    for (; s < n_splits; s += 4) acc = fmaf(part_o[(base + s) * DH + d], w_s[s], acc);
+    acc_s[g][d] = acc;
+    __syncthreads();
+    if (g == 0) {
+        acc = acc_s[0][d] + acc_s[1][d] + acc_s[2][d] + acc_s[3][d];
+        o[((int64_t)bat * H + head) * DH + d] = f_to_bf(L > 0.f ? acc / L : 0.f);
+    }
 }
 
 static int attn_check_strides(int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
@@ -727,8 +864,13 @@ extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v,
     a.n_qblocks = 1;
     a.dyn_pos = dyn_pos; a.part_o = part_o; a.part_ml = part_ml; a.n_splits = (int)n_splits; a.nbh = (int)(B * H);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)n_splits, (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(128), 0, s, part_o, part_ml,
+    // EVO_ATTN_DECODE_FORM=0 keeps the MFMA split kernel (measurement builds); default: the streaming kernel, one split per wave
+    static const int form = [] { const char* e = getenv("EVO_ATTN_DECODE_FORM"); return e ? atoi(e) : 1; }();
+    if (form != 0)
+        hipLaunchKernelGGL(attn_decode_stream_kernel, dim3((unsigned)((n_splits + 3) / 4), (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)n_splits, (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(512), 0, s, part_o, part_ml,
                        (uint16_t*)o, (int)H, (int)n_splits);
     return evo_launch_status();
 }

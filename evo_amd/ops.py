@@ -520,8 +520,10 @@ class HipOps:
             if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
                 raise RuntimeError(f"attention_decode {nm}: need a ROCm bf16 tensor with a dense last dim")
         Tk = k.shape[1]
-        if n_splits is None:                     # enough workgroups to cover the chip, at most one per key tile
-            n_splits = max(1, min((Tk + 63) // 64, -(-512 // (B * H))))
+        if n_splits is None:                     # one split per WAVE of the streaming kernel, whole workgroups of four, at most
+            # one per 64-key block.  Measured on MI355X (tools/experiments/attn_decode_bench.py): 64 is best from 8 k to 131 k keys
+            # at batch 1-3 (a wave is latency-bound on its own blocks: more, shorter waves win until the partials cost more)
+            n_splits = min(((Tk + 63) // 64 + 3) // 4 * 4, 64 if B * H <= 128 else 32)
         o = torch.empty(B, 1, H, hd, dtype=torch.bfloat16, device=q.device)
         part_o = torch.empty(B, H, n_splits, hd, dtype=torch.float32, device=q.device)
         part_ml = torch.empty(B, H, n_splits, 2, dtype=torch.float32, device=q.device)
