@@ -684,9 +684,16 @@ __global__ __launch_bounds__(256) void attn_decode_stream_kernel(AttnArgs a) {
                                                              // megabytes apart at equal offsets: 591 us instead of 429 at 131 k keys)
     const int ks = lane >> 4, dc = lane & 15;
     const uint4 qv = ((const uint4*)(a.q + bat * a.q_sb + head * a.q_sh))[dc];
-    const unsigned char* kp = (const unsigned char*)(a.k + bat * a.k_sb + head * a.k_sh) + dc * 16;
-    const unsigned char* vp = (const unsigned char*)(a.v + bat * a.v_sb + head * a.v_sh) + dc * 16;
-    const int64_t kst = a.k_st * 2, vst = a.v_st * 2;
+    // wave-uniform base (SGPR pair) + 32-bit lane offset: one VGPR per address instead of two (the host checks Tk * stride < 4 GiB)
+    typedef const __attribute__((address_space(1))) unsigned char* gptr_t;
+    const gptr_t kp = (gptr_t)(uint64_t)(a.k + bat * a.k_sb + head * a.k_sh);
+    const gptr_t vp = (gptr_t)(uint64_t)(a.v + bat * a.v_sb + head * a.v_sh);
+    const uint32_t kst = (uint32_t)(a.k_st * 2), vst = (uint32_t)(a.v_st * 2), dco = (uint32_t)dc * 16;
+    typedef unsigned int attn_u32x4 __attribute__((ext_vector_type(4)));
+    auto ld16 = [](gptr_t base, uint32_t off) {
+        const attn_u32x4 t = *(const __attribute__((address_space(1))) attn_u32x4*)(base + off);
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    };
     float m_run = -INFINITY, l_run = 0.f;
     float o[8];
 #pragma unroll
@@ -698,13 +705,13 @@ __global__ __launch_bounds__(256) void attn_decode_stream_kernel(AttnArgs a) {
         for (int i = 0; i < 16; ++i) {
             int64_t key = k0 + 4 * i;
             key = key < n_keys ? key : n_keys - 1;           // a ragged last block re-reads the last key (masked below)
-            kr[i] = *(const uint4*)(kp + key * kst);
+            kr[i] = ld16(kp, (uint32_t)key * kst + dco);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             int64_t key = k0 + 4 * i;
             key = key < n_keys ? key : n_keys - 1;
-            vr[i] = *(const uint4*)(vp + key * vst);
+            vr[i] = ld16(vp, (uint32_t)key * vst + dco);
         }
         float sc[16];
         float mb = -INFINITY;
@@ -866,7 +873,7 @@ extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v,
     hipStream_t s = (hipStream_t)stream;
     // EVO_ATTN_DECODE_FORM=0 keeps the MFMA split kernel (measurement builds); default: the streaming kernel, one split per wave
     static const int form = [] { const char* e = getenv("EVO_ATTN_DECODE_FORM"); return e ? atoi(e) : 1; }();
-    if (form != 0)
+    if (form != 0 && Tk * k_st * 2 < 0xffffffffll && Tk * v_st * 2 < 0xffffffffll)
         hipLaunchKernelGGL(attn_decode_stream_kernel, dim3((unsigned)((n_splits + 3) / 4), (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)n_splits, (unsigned)H, (unsigned)B), dim3(256), 0, s, a);
