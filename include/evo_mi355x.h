@@ -136,7 +136,9 @@ int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* 
  *            row b's query sits at p_b = dyn_pos[b] and sees keys [0, p_b] (Tk is then only the cache capacity
  *            bound).  The launch no longer depends on the positions, so a captured hipGraph can be replayed for
  *            every token, and rows may be at DIFFERENT positions (continuous batching of decode streams);
- *   part_o [B, H, n_splits, 128] f32 and part_ml [B, H, n_splits, 2] f32: caller-owned workspace. */
+ *   part_o [B, H, n_splits, 128] f32 and part_ml [B, H, n_splits, 2] f32: caller-owned workspace;
+ *   n_splits <= 1024.  A bandwidth kernel (the KV cache is read once, 512 * H bytes per key): a WAVE owns a split = every
+ *   n_splits-th 64-key block, requests the 32 KiB of a block at once and needs neither LDS nor barriers. */
 int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
                          int64_t B, int64_t H, int64_t Tk,
                          int64_t q_sb, int64_t q_sh,
