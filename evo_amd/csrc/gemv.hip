@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint4* __restrict__ x, 
     }
 }
 
-// STAGE: wave m of the workgroup (m < M <= 4) normalises batch row m ONCE into LDS and every wave's trips read it from there.
+// STAGE: wave m of the workgroup normalises batch row m (and m + 4 when M > 4) ONCE into LDS and every wave's trips read it from there.
 // Two things were wrong with every wave rebuilding the normalised slices itself: the sum of squares was a loop of one 16-byte
 // load + s_waitcnt vmcnt(0) per 64-vector slice -- eight dependent L2 round trips per row, queued BEHIND the weight prefetch
 // (vmcnt retires in order), ~6 us of every wave's life at M = 1 -- and at M >= 2 the per-trip re-normalisation made the
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     }
     // (STAGE) the staging wave's x / scale requests go out first, so they come back first
     uint4 st_x[8], st_s[8];
-    const bool stager = STAGE && wave < M;
+    const bool stager = STAGE && wave < M;                   // (M > 4: waves 0-3 take rows 4-7 in a second round)
     if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
     __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
@@ -265,6 +265,12 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict_
     };
     if (STAGE) {
         if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        if (M > 4) {                                         // batch rows 4-7: a second round for the same waves
+            for (int r = wave + 4; r < M; r += 4) {
+                gv_stage_load(x + (int64_t)r * nvec, scale, nvec, lane, st_x, st_s);
+                gv_stage_finish(gv_xn + r * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+            }
+        }
         GV_WG_BARRIER();
         if (n0 >= N) return;
         __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     for (int r = 0; r < GV_R; ++r) wrow[r] = w + (int64_t)(h * 3 * HDc + (r / CPW) * HDc + j0 + (r % CPW)) * nvec;
     // (STAGE) the staging wave's x / scale requests go out first, so they come back first
     uint4 st_x[8], st_s[8];
-    const bool stager = STAGE && wave < M;
+    const bool stager = STAGE && wave < M;                   // (M > 4: waves 0-3 take rows 4-7 in a second round)
     if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
     __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // the first trip's weights are requested BEFORE the norm pass (which only touches x, in L2): the HBM stream starts at
@@ -385,6 +391,12 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
     };
     if (STAGE) {
         if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        if (M > 4) {                                         // batch rows 4-7: a second round for the same waves
+            for (int r = wave + 4; r < M; r += 4) {
+                gv_stage_load(x + (int64_t)r * nvec, scale, nvec, lane, st_x, st_s);
+                gv_stage_finish(gv_xn + r * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+            }
+        }
         GV_WG_BARRIER();
         if (unit >= D / CPW) return;
         __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
     }
     // (STAGE) the staging wave's x / scale requests go out first, so they come back first
     uint4 st_x[8], st_s[8];
-    const bool stager = STAGE && wave < M;
+    const bool stager = STAGE && wave < M;                   // (M > 4: waves 0-3 take rows 4-7 in a second round)
     if (stager) gv_stage_load(x + (int64_t)wave * nvec, scale, nvec, lane, st_x, st_s);
     __builtin_amdgcn_sched_barrier(0);                       // (requests retire in issue order: keep these ahead of the weights)
     // first trip's weights before the norm pass, every later trip one ahead (see gemv_norm_kernel)
@@ -547,6 +559,12 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
     };
     if (STAGE) {
         if (stager) gv_stage_finish(gv_xn + wave * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+        if (M > 4) {                                         // batch rows 4-7: a second round for the same waves
+            for (int r = wave + 4; r < M; r += 4) {
+                gv_stage_load(x + (int64_t)r * nvec, scale, nvec, lane, st_x, st_s);
+                gv_stage_finish(gv_xn + r * nvec, nvec, lane, eps, inv_sqrt_d, st_x, st_s);
+            }
+        }
         GV_WG_BARRIER();
         if (n0 >= I) return;
         __builtin_amdgcn_sched_barrier(0);                   // (the second trip's requests stay below the staging: its registers are free now)
@@ -700,7 +718,8 @@ static void gemv_launch(const void* x, const void* w, const void* bias, const vo
 
 extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w, const void* bias, void* y,
                                             int64_t M, int64_t N, int64_t K, float eps, void* stream) {
-    if (M < 1 || M > 4 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
+    if (M < 1 || M > 8 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
+    if (M > 4 && K != 4096) return -1;                       // batches of 5-8 rows exist in the LDS-staged form only
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(((N + 3) / 4 + 3) / 4)), block(256);
     const float isd = 1.0f / sqrtf((float)K);
@@ -713,12 +732,20 @@ extern "C" int evo_norm_linear_small_m_bf16(const void* x, const void* scale, co
     else                                                                                                      \
         hipLaunchKernelGGL((gemv_norm_kernel<MM, 4, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
                            (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd)
+#define EVO_NLS(MM)                                                                                           \
+    hipLaunchKernelGGL((gemv_norm_kernel<MM, 4, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
+                       (const uint4*)w, (const uint16_t*)bias, (uint16_t*)y, (int)N, (int)(K / 8), eps, isd)
     switch (M) {
         case 1: EVO_NL(1); break;
         case 2: EVO_NL(2); break;
         case 3: EVO_NL(3); break;
-        default: EVO_NL(4); break;
+        case 4: EVO_NL(4); break;
+        case 5: EVO_NLS(5); break;
+        case 6: EVO_NLS(6); break;
+        case 7: EVO_NLS(7); break;
+        default: EVO_NLS(8); break;
     }
+#undef EVO_NLS
 #undef EVO_NL
     return evo_launch_status();
 }
@@ -727,7 +754,8 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
                                               void* fir_state, float* iir_state, const void* fir_w, const void* fir_b,
                                               const float* poles, const float* residues, const void* dskip, void* y,
                                               int64_t M, int64_t D, int64_t n_heads, float eps, void* stream) {
-    if (M < 1 || M > 4 || D <= 0 || D != n_heads * 128 || D % 8 != 0) return -1;
+    if (M < 1 || M > 8 || D <= 0 || D != n_heads * 128 || D % 8 != 0) return -1;
+    if (M > 4 && D != 4096) return -1;                       // batches of 5-8 rows exist in the LDS-staged form only
     hipStream_t s = (hipStream_t)stream;
     // channels per wave, measured under a hipGraph on MI355X (tools/experiments/hyena_decode_cpw_bench.py): one channel per wave
     // (twice the waves, half the bytes in flight each) is 5 % faster at M = 1 and 6 % at M = 4, two channels win at M = 2
@@ -751,7 +779,11 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
         case 1: if (stage) EVO_HD(1, GEMV_HYENA_CPW_STAGED1, true); else EVO_HD(1, 1, false); break;
         case 2: if (stage) EVO_HD(2, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(2, 2, false); break;
         case 3: if (stage) EVO_HD(3, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(3, 2, false); break;
-        default: if (stage) EVO_HD(4, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(4, 1, false); break;
+        case 4: if (stage) EVO_HD(4, GEMV_HYENA_CPW_STAGED, true); else EVO_HD(4, 1, false); break;
+        case 5: EVO_HD(5, 1, true); break;
+        case 6: EVO_HD(6, 1, true); break;
+        case 7: EVO_HD(7, 1, true); break;
+        default: EVO_HD(8, 1, true); break;
     }
 #undef EVO_HD
     return evo_launch_status();
@@ -759,7 +791,8 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
 
 static int mlp_gate_launch(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
                            float eps, hipStream_t s) {
-    if (M < 1 || M > 4 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
+    if (M < 1 || M > 8 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
+    if (M > 4 && !(scale && K == 4096)) return -1;           // batches of 5-8 rows exist in the LDS-staged form only
     const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
     const float isd = 1.0f / sqrtf((float)K);
     const size_t lds = (size_t)M * K * 2;
@@ -774,12 +807,20 @@ static int mlp_gate_launch(const void* x, const void* scale, const void* w12, vo
     else                                                                                                      \
         hipLaunchKernelGGL((gemv_gate_kernel<MM, false, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)nullptr, \
                            (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), 0.f, 0.f)
+#define EVO_MGS(MM)                                                                                           \
+    hipLaunchKernelGGL((gemv_gate_kernel<MM, true, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
+                       (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd)
     switch (M) {
         case 1: EVO_MG(1); break;
         case 2: EVO_MG(2); break;
         case 3: EVO_MG(3); break;
-        default: EVO_MG(4); break;
+        case 4: EVO_MG(4); break;
+        case 5: EVO_MGS(5); break;
+        case 6: EVO_MGS(6); break;
+        case 7: EVO_MGS(7); break;
+        default: EVO_MGS(8); break;
     }
+#undef EVO_MGS
 #undef EVO_MG
     return evo_launch_status();
 }

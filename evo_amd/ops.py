@@ -456,10 +456,10 @@ class HipOps:
 
     def hyena_decode_fused(self, x, norm_scale, eps, proj_w, proj_b, fir_state, iir_state, fir_w, fir_b, poles,
                            residues, dskip, n_heads: int) -> torch.Tensor:
-        """One decode token through pre-norm + projections + FIR/modal step + gate in ONE launch (M = batch <= 4);
+        """One decode token through pre-norm + projections + FIR/modal step + gate in ONE launch (M = batch <= 4, or <= 8 at D = 4096);
         states are updated in place.  Falls back to the two kernels otherwise."""
         M, D = x.shape
-        ok = (1 <= M <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and proj_w.is_contiguous()
+        ok = ((1 <= M <= 4 or (M <= 8 and D == 4096)) and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and proj_w.is_contiguous()
               and proj_w.dtype == torch.bfloat16 and norm_scale.dtype == torch.bfloat16 and proj_b is not None
               and fir_state.dtype == torch.bfloat16 and fir_state.is_contiguous() and fir_state.shape[0] == M
               and iir_state.dtype == torch.complex64 and iir_state.is_contiguous() and iir_state.shape[0] == M
@@ -540,7 +540,7 @@ class HipOps:
         """linear(rmsnorm(x) * scale, w, b).  Decode-sized batches (M <= 4) with a wide layer take ONE weight-streaming
         launch that rebuilds the normalised row on the fly; everything else is the two kernels."""
         M, K = x.shape
-        if (1 <= M <= 4 and w.shape[0] > 4096 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+        if ((1 <= M <= 4 or (M <= 8 and K == 4096)) and w.shape[0] > 4096 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
                 and scale.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and scale.is_contiguous()
                 and K % 8 == 0):
             y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device)
@@ -558,7 +558,7 @@ class HipOps:
         (norm,) dense layer and gate kernel."""
         M, K = x.shape
         I = w12.shape[0] // 2
-        if (1 <= M <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and w12.dtype == torch.bfloat16 and x.is_contiguous()
+        if ((1 <= M <= 4 or (M <= 8 and K == 4096 and norm_scale is not None)) and x.is_cuda and x.dtype == torch.bfloat16 and w12.dtype == torch.bfloat16 and x.is_contiguous()
                 and w12.is_contiguous() and K % 8 == 0 and I % 2 == 0
                 and (norm_scale is None or (norm_scale.dtype == torch.bfloat16 and norm_scale.is_contiguous()))):
             a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)

@@ -266,7 +266,7 @@ class StripedHyena(nn.Module):
                 torch.sin(freqs).to(torch.bfloat16).float().contiguous())
 
     # ------------------------------------------------------------------ blocks
-    DECODE_ROWS = 4          # batches this small take the fused single-token launches (csrc/gemv.hip)
+    DECODE_ROWS = 8          # batches this small take the fused single-token launches (csrc/gemv.hip; 5-8 rows at D = 4096 only)
 
     def _mixer_out_(self, blk, x2d, y, w, bias, mfma=False):
         """x += y @ w^T (the mixer's output projection); returns the bias still to be added (folded into the next

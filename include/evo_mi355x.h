@@ -166,7 +166,7 @@ int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const v
 
 /* ---- Hyena mixer input of one decode step, fused ---------------------------------------------------------------
  * replaces pre-norm + projections GEMV + step_fir + step_iir of the single-token forward   [REF evo/generation.py:111-114,138-155]
- * x [M, D] bf16 residual rows (M = batch, 1 <= M <= 4), norm_scale [D], proj_w [3D, D], proj_b [3D] -> y [M, D] bf16;
+ * x [M, D] bf16 residual rows (M = batch, 1 <= M <= 4; up to 8 at D = 4096), norm_scale [D], proj_w [3D, D], proj_b [3D] -> y [M, D] bf16;
  * fir_state [M, 3D, 2] bf16 and iir_state [M, D, 8] complex64 are updated in place.  Bit-identical to
  * evo_norm_linear_small_m_bf16 followed by evo_hyena_step. */
 int evo_hyena_decode_fused_small_m(const void* x, const void* norm_scale, const void* proj_w, const void* proj_b,
@@ -177,7 +177,8 @@ int evo_hyena_decode_fused_small_m(const void* x, const void* norm_scale, const 
 /* ---- RMSNorm + dense layer, decode form ----------------------------------------------------------------------
  * replaces the pre-mixer RMSNorm and the projection GEMV of the single-token forward     [REF evo/generation.py:151-155;
  *                                                                                   evo/configs/evo-1-8k-base_inference.yml:13]
- * y [M, N] = bf16(scale * x / (rms(x) + eps)) . w [N, K]^T (+ bias [N]);  1 <= M <= 4, K % 8 == 0, all bf16.  The
+ * y [M, N] = bf16(scale * x / (rms(x) + eps)) . w [N, K]^T (+ bias [N]);  1 <= M <= 4 (up to 8 at K = 4096), K % 8 == 0,
+ * all bf16.  The
  * normalised row is bit-identical to what evo_rmsnorm_bf16 stores (same reduction order). */
 int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w, const void* bias, void* y,
                                  int64_t M, int64_t N, int64_t K, float eps, void* stream);
@@ -189,7 +190,7 @@ int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w
  * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them. */
 int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, void* stream);
 /* same with the post-mixer RMSNorm folded in: x is the residual row, `scale` [K] the norm weight (bit-identical to
- * evo_rmsnorm_bf16 followed by evo_mlp_gate_small_m_bf16). */
+ * evo_rmsnorm_bf16 followed by evo_mlp_gate_small_m_bf16); this form also takes 5 <= M <= 8 at K = 4096. */
 int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I,
                                    int64_t K, float eps, void* stream);
 

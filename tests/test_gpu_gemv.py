@@ -61,11 +61,12 @@ def test_mlp_gate_fused_matches_unfused_and_fp64(M, I, K):
     assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
 
 
-@pytest.mark.parametrize("M", [1, 2, 4, 7])
+@pytest.mark.parametrize("M", [1, 2, 4, 5, 7, 8])
 @pytest.mark.parametrize("N,K", [(12288, 4096), (4104, 264)])
 def test_norm_linear_fused_is_bitwise_the_two_kernels(M, N, K):
-    """RMSNorm folded into the weight-streaming dense layer (M <= 4, N > 4096): the normalised row is rebuilt with the
-    rmsnorm kernel's own reduction order, so the result equals rmsnorm -> linear bit for bit (M = 7: the fallback)."""
+    """RMSNorm folded into the weight-streaming dense layer (M <= 4, or M <= 8 at K = 4096; N > 4096): the normalised row is
+    rebuilt with the rmsnorm kernel's own reduction order, so the result equals rmsnorm -> linear bit for bit up to M = 4
+    (beyond: the two-kernel path sums on the MFMA; M = 7 at K = 264: the fallback)."""
     from evo_amd.ops import default_ops
     ops = default_ops()
     g = torch.Generator().manual_seed(M * 13 + N + K)
@@ -75,14 +76,17 @@ def test_norm_linear_fused_is_bitwise_the_two_kernels(M, N, K):
     b = torch.randn(N, generator=g).bfloat16().to(DEV)
     got = ops.norm_linear(x, scale, 1e-6, w, b)
     two = ops.linear(ops.rmsnorm(x.clone(), None, scale, 1e-6), w, b)
-    assert torch.equal(got, two)
+    if M <= 4 or K != 4096:
+        assert torch.equal(got, two)
+    else:     # 5-8 rows at K = 4096: the fused launch sums on the VALU, the two-kernel path on the MFMA (other order)
+        assert (got.double() - two.double()).abs().max().item() <= 2.0 ** -7 * two.double().abs().max().item()
     xd = x.double()
     n = (scale.double() * xd / (xd.pow(2).mean(-1, keepdim=True).sqrt() + 1e-6)).bfloat16().double()
     want = n @ w.double().t() + b.double()
     assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
 
 
-@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("M", [1, 3, 4, 6, 8])
 def test_norm_mlp_gate_fused_is_bitwise_norm_then_gate(M):
     from evo_amd.ops import default_ops
     ops = default_ops()
@@ -93,7 +97,15 @@ def test_norm_mlp_gate_fused_is_bitwise_norm_then_gate(M):
     w12 = (torch.randn(2 * I, K, generator=g) * (1.5 / K ** 0.5)).bfloat16().to(DEV)
     got = ops.mlp_gate(x, w12, scale, 1e-6)
     two = ops.mlp_gate(ops.rmsnorm(x.clone(), None, scale, 1e-6), w12)
-    assert torch.equal(got, two)
+    if M <= 4:
+        assert torch.equal(got, two)
+    else:     # 5-8 rows: fused = VALU sums, unfused = MFMA sums; both round l1 / l2 to bf16 before the gate
+        xd = ops.rmsnorm(x.clone(), None, scale, 1e-6).double()
+        u, v = (xd @ w12[:I].double().t()).bfloat16().double(), (xd @ w12[I:].double().t()).bfloat16().double()
+        want = torch.nn.functional.gelu(u) * v
+        err = (got.double() - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -6 + 2e-3 * want.abs().max()).all())
+        assert ((got.double() - want).norm() / want.norm()).item() < 4e-3
 
 
 def test_linear_residual_with_bias_small_m():
@@ -138,3 +150,42 @@ def test_hyena_decode_fused_is_bitwise_the_separate_kernels(M):
         yb = ops.hyena_step(z, fs_b, st_b, fir_w, fir_b, poles, res, dskip, H)
         assert torch.equal(ya, yb), f"step {step}"
         assert torch.equal(fs_a, fs_b) and torch.equal(torch.view_as_real(st_a), torch.view_as_real(st_b))
+
+
+@pytest.mark.parametrize("M", [1, 3, 4, 5, 8])
+def test_hyena_decode_fused_full_width(M):
+    """D = 4096 (the LDS-staged launches, incl. 5-8 batch rows): outputs and carried states against the separate kernels --
+    bit for bit up to M = 4 (same summation order), to bf16 rounding beyond (the separate projection runs on the MFMA)."""
+    import math
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    D, H = 4096, 32
+    g = torch.Generator().manual_seed(100 + M)
+    scale = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16().to(DEV)
+    w = (torch.randn(3 * D, D, generator=g) / D ** 0.5).bfloat16().to(DEV)
+    b = (torch.randn(3 * D, generator=g) * 0.1).bfloat16().to(DEV)
+    fir_w = (torch.randn(3 * D, 3, generator=g) * 0.3).bfloat16().to(DEV)
+    fir_b = (torch.randn(3 * D, generator=g) * 0.1).bfloat16().to(DEV)
+    mag = 1.0 - 10.0 ** (-5.0 + 4.0 * torch.rand(D, 8, generator=g))
+    ang = (torch.rand(D, 8, generator=g) * 2 - 1) * math.pi
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous().to(DEV)
+    res = (torch.randn(D, 8, 2, generator=g) * 0.25).float().contiguous().to(DEV)
+    dskip = (torch.randn(D, generator=g) * 0.5).bfloat16().to(DEV)
+    fs_a = (torch.randn(M, 3 * D, 2, generator=g)).bfloat16().to(DEV)
+    st_a = torch.view_as_complex(torch.randn(M, D, 8, 2, generator=g).contiguous()).to(DEV)
+    fs_b, st_b = fs_a.clone(), st_a.clone()
+    for step in range(2):
+        x = (torch.randn(M, D, generator=g) * 2).bfloat16().to(DEV)
+        ya = ops.hyena_decode_fused(x, scale, 1e-6, w, b, fs_a, st_a, fir_w, fir_b, poles, res, dskip, H)
+        z = ops.linear(ops.rmsnorm(x.clone(), None, scale, 1e-6), w, b)
+        yb = ops.hyena_step(z, fs_b, st_b, fir_w, fir_b, poles, res, dskip, H)
+        if M <= 4:
+            assert torch.equal(ya, yb), f"step {step}"
+            assert torch.equal(fs_a, fs_b) and torch.equal(torch.view_as_real(st_a), torch.view_as_real(st_b))
+        else:
+            tol = 2.0 ** -6
+            assert (ya.double() - yb.double()).abs().max().item() <= tol * yb.double().abs().max().item() + 1e-2
+            ra, rb = torch.view_as_real(st_a).double(), torch.view_as_real(st_b).double()
+            assert (ra - rb).abs().max().item() <= tol * rb.abs().max().item()
+            assert (fs_a.double() - fs_b.double()).abs().max().item() <= tol * fs_b.double().abs().max().item()
+            fs_b.copy_(fs_a); st_b.copy_(st_a)      # (keep the two histories from drifting apart on rounding differences)
