@@ -415,6 +415,10 @@ def bench_generation(device, prompt=8192, new=1024):
            "prefill_ms": t_pre * 1e3, "prefill_nt_per_s": prompt / t_pre, "decode_ms_per_token": dec * 1e3,
            "decode_tokens_per_s": 1.0 / dec, "end_to_end_s": t_all,
            "weight_stream_GBps": 12.906 / dec, "hbm_frac": 12.906e9 / dec / 1e9 / HBM_PEAK_GBS,
+           # decode is HBM-bound on the weights (12.9 GB/step) PLUS the KV read -- 3 attention layers x keys x
+           # 2 (K, V) x 4096 x 2 B; averaged over the generated positions
+           "kv_read_GB_per_token_avg": 3 * (prompt + new / 2) * 2 * 4096 * 2 / 1e9,
+           "hbm_frac_with_kv": (12.906e9 + 3 * (prompt + new / 2) * 2 * 4096 * 2) / dec / 1e9 / HBM_PEAK_GBS,
            "top_k4_decode_ms_per_token": dec4 * 1e3,
            "graph_engaged": getattr(model, "_dgraph", None) is not None}
     del model
