@@ -205,6 +205,68 @@ extern "C" int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_
     return evo_launch_status();
 }
 
+// ---- decode step: rotary on q and k at each row's own position + append of (k, v) to the KV cache, one launch.
+// The separate path built a [B, hd/2] cos / sin table with six small ATen launches per token, ran rope_kernel and then an
+// indexed copy per attention layer (~45 us of launch-bound kernels per token).  Same arithmetic: angle = (p / scaling) *
+// inv_freq in fp32, cosf / sinf, rounded to bf16 values like flash-attn's cached table, then rope_kernel's expression.
+__global__ __launch_bounds__(256) void rope_append_decode_kernel(uint4* __restrict__ qkv, uint4* __restrict__ kv,
+                                                                 const int64_t* __restrict__ pos,
+                                                                 const float* __restrict__ inv_freq, float scaling, int B,
+                                                                 int H, int hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw,
+                                                                 int64_t kv_sh) {   // kv strides in 16-byte vectors
+    const int half_vec = hd / 16;
+    const int total = B * H * half_vec;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % half_vec;
+    const int h = (i / half_vec) % H;
+    const int b = i / (half_vec * H);
+    const int64_t p = pos[b];
+    float t = (float)p;
+    if (scaling != 1.0f) t = t / scaling;
+    float co[8], si[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float f = t * inv_freq[c * 8 + e];
+        co[e] = round_bf(cosf(f));
+        si[e] = round_bf(sinf(f));
+    }
+    const int rv = hd / 8;                                   // vectors per head row
+    uint4* krow = kv + b * kv_sb + p * kv_st + h * kv_sh;
+    uint4* vrow = krow + kv_sw;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {                // q, k
+        const int64_t row_vec = (((int64_t)b * 3 + which) * H + h) * rv;
+        float x0[8], x1[8], o0[8], o1[8];
+        unpack8(qkv[row_vec + c], x0);
+        unpack8(qkv[row_vec + half_vec + c], x1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o0[e] = x0[e] * co[e] - x1[e] * si[e];
+            o1[e] = x0[e] * si[e] + x1[e] * co[e];
+        }
+        const uint4 r0 = pack8(o0), r1 = pack8(o1);
+        qkv[row_vec + c] = r0;
+        qkv[row_vec + half_vec + c] = r1;
+        if (which == 1) { krow[c] = r0; krow[half_vec + c] = r1; }
+    }
+    const int64_t vvec = (((int64_t)b * 3 + 2) * H + h) * rv;
+    vrow[c] = qkv[vvec + c];
+    vrow[half_vec + c] = qkv[vvec + half_vec + c];
+}
+
+extern "C" int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const float* inv_freq, float scaling,
+                                           int64_t B, int64_t H, int64_t hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw,
+                                           int64_t kv_sh, void* stream) {
+    if (B <= 0 || H <= 0 || hd <= 0 || hd % 16 != 0 || !qkv || !kv || !pos || !inv_freq || scaling <= 0.f) return -1;
+    if ((kv_sb % 8) || (kv_st % 8) || (kv_sw % 8) || (kv_sh % 8) || B * H * (hd / 16) > 0x7fffffff) return -1;
+    const int total = (int)(B * H * (hd / 16));
+    hipLaunchKernelGGL(rope_append_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (uint4*)qkv, (uint4*)kv, pos, inv_freq, scaling, (int)B, (int)H, (int)hd, kv_sb / 8, kv_st / 8, kv_sw / 8,
+                       kv_sh / 8);
+    return evo_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------- gelu gate
 __global__ __launch_bounds__(128) void gelu_gate_kernel(const uint4* __restrict__ g, uint4* __restrict__ a, int64_t M,
                                                         int ivec) {

@@ -43,10 +43,11 @@ _SIGNATURES = {
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_unembed_logprob_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_hyena_mfma": ([_PTR] * 7 + [_I64] * 4 + [_PTR], _c.c_int),
+    "evo_rope_append_decode_bf16": ([_PTR] * 4 + [_F32] + [_I64] * 7 + [_PTR], _c.c_int),
 }
 
 _LIB = None
-ABI_VERSION = 2          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 3          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -486,6 +487,21 @@ class HipOps:
         _check(self.lib.evo_rope_qk_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, T, H, hd, _stream()),
                "evo_rope_qk_bf16")
         return qkv
+
+    def rope_append_decode(self, qkv: torch.Tensor, kv: torch.Tensor, pos: torch.Tensor, inv_freq: torch.Tensor,
+                           scaling: float) -> None:
+        """One decode token per stream: NeoX rotary on q and k of qkv [B,1,3,H,hd] (in place) at position pos[b] (/ scaling) and
+        kv[b, pos[b]] = (k, v) -- kv [>=B, cap, 2, H, hd].  One launch; bit-identical to the rotary table + rope_ + indexed copy."""
+        self._need(qkv, torch.bfloat16, "rope_append_decode qkv")
+        B, T, three, H, hd = qkv.shape
+        if T != 1 or three != 3 or kv.dtype != torch.bfloat16 or not kv.is_cuda or kv.stride(-1) != 1 or kv.shape[0] < B:
+            raise RuntimeError("rope_append_decode: expects qkv [B,1,3,H,hd] and a bf16 KV cache [>=B,cap,2,H,hd]")
+        if pos.dtype != torch.int64 or not pos.is_cuda or pos.numel() != B or not pos.is_contiguous():
+            raise RuntimeError("rope_append_decode pos: need a contiguous device int64 tensor with B entries")
+        self._need(inv_freq, torch.float32, "rope_append_decode inv_freq")
+        _check(self.lib.evo_rope_append_decode_bf16(qkv.data_ptr(), kv.data_ptr(), pos.data_ptr(), inv_freq.data_ptr(),
+                                                    float(scaling), B, H, hd, kv.stride(0), kv.stride(1), kv.stride(2),
+                                                    kv.stride(3), _stream()), "evo_rope_append_decode_bf16")
 
     def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos0: int) -> torch.Tensor:
         """Causal attention; q [B,Tq,H,128], k/v [B,Tk,H,128] (strided views allowed, last dim dense)."""

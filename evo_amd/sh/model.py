@@ -249,15 +249,19 @@ class StripedHyena(nn.Module):
             hit = self._rows = torch.arange(max(B, 8), dtype=torch.int64, device=device)
         return hit[:B]
 
+    def _inv_freq(self, dev) -> torch.Tensor:
+        inv = getattr(self, "_inv_freq_dev", None)
+        if inv is None or inv.device != torch.device(dev):
+            hd = self.head_dim
+            inv = 1.0 / (self.rotary_base ** (torch.arange(0, hd, 2, dtype=torch.float32, device=dev) / hd))
+            self._inv_freq_dev = inv
+        return inv
+
     def _rotary_dyn(self, pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Same table for positions held in device memory (int64 [n]: one per decode stream) -- no host read,
         graph-capturable.  Returns cos, sin [n, hd/2]."""
         hd = self.head_dim
-        dev = pos.device
-        inv = getattr(self, "_inv_freq_dev", None)
-        if inv is None or inv.device != dev:
-            inv = 1.0 / (self.rotary_base ** (torch.arange(0, hd, 2, dtype=torch.float32, device=dev) / hd))
-            self._inv_freq_dev = inv
+        inv = self._inv_freq(pos.device)
         t = pos.to(torch.float32)
         if self.rotary_scaling != 1.0:
             t = t / self.rotary_scaling
@@ -389,10 +393,14 @@ class StripedHyena(nn.Module):
             # position-independent decode step (hipGraph replay, continuous batching): one position PER ROW, in
             # device memory.  The rotary kernel indexes its table by token, so the B rows are presented as one
             # sequence of B tokens with the per-row table.
-            cos, sin = getattr(cache, "_rot_dyn", None) or self._rotary_dyn(pos)
-            ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin)
             kv = cache.key_value_memory_dict[i][:B]
-            kv[self._row_index(B, x2d.device), pos] = qkv[:, 0, 1:3]
+            if hasattr(ops, "rope_append_decode") and pos.numel() == B:
+                # rotary at each row's position + the KV append in one launch (no per-step cos / sin table)
+                ops.rope_append_decode(qkv, kv, pos, self._inv_freq(x2d.device), self.rotary_scaling)
+            else:
+                cos, sin = getattr(cache, "_rot_dyn", None) or self._rotary_dyn(pos)
+                ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin)
+                kv[self._row_index(B, x2d.device), pos] = qkv[:, 0, 1:3]
             a = ops.attention_decode(q, kv[:, :, 0], kv[:, :, 1], pos=pos).view(B, D)
         else:
             cos, sin = self._rotary(off, T, x2d.device)
@@ -430,7 +438,7 @@ class StripedHyena(nn.Module):
         mha_c = inference_params_dict["mha"] if inference_params_dict is not None else None
         hy_c = inference_params_dict["hyena"] if inference_params_dict is not None else None
         dyn = T == 1 and mha_c is not None and getattr(mha_c, "pos_tensor", None) is not None
-        if dyn:                                   # one rotary table per decode step, shared by the attention layers
+        if dyn and not hasattr(ops, "rope_append_decode"):   # (fallback path) one rotary table per decode step for all layers
             mha_c._rot_dyn = self._rotary_dyn(mha_c.pos_tensor)
         taps = getattr(self, "block_taps", None)     # debugging / parity hook: residual stream entering every block
         try:
@@ -523,6 +531,7 @@ class StripedHyena(nn.Module):
                 st["pos"].fill_(off)
                 mha.pos_tensor = st["pos"]
                 self._row_index(B, dev)             # (allocated outside the capture)
+                self._inv_freq(dev)
                 g = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(g):

@@ -26,8 +26,9 @@ extern "C" {
 
 /* ABI version; bumped when a signature changes (the binding refuses a library whose version differs).
  *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_seg_state / evo_hyena_apply gained `mask`;
- *      evo_unembed_logprob_bf16 and evo_hyena_mfma added. */
-#define EVO_ABI_VERSION 2
+ *      evo_unembed_logprob_bf16 and evo_hyena_mfma added.
+ *   3: evo_rope_append_decode_bf16 added; the fused decode launches take up to 8 rows at K = 4096. */
+#define EVO_ABI_VERSION 3
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -115,6 +116,17 @@ int evo_hyena_step(const void* z_t, void* fir_state, float* iir_state,
  * pos0..pos0+T-1 (already divided by the interpolation factor, already rounded to bf16 values). */
 int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t,
                      int64_t B, int64_t T, int64_t H, int64_t hd, void* stream);
+
+/* decode form: rotary on the q and k rows of ONE token per stream, each at its own position, and the append of (k, v) to
+ * the KV cache, in one launch                                  [REF evo/generation.py:138-155; flash_attn_with_kvcache's
+ *                                                              rotary + cache-update arguments]
+ *   qkv [B, 3, H, hd] bf16 contiguous (q and k rotated in place); kv = the cache [.., cap, 2, H, hd] bf16 with element strides
+ *   (batch, token, k|v, head), each a multiple of 8; pos [B] device int64: row b is written at token pos[b] (< cap: the caller's
+ *   bound); inv_freq [hd/2] f32; angle = (pos / scaling) * inv_freq, cos / sin rounded to bf16 values as the cached tables are.
+ *   Bit-identical to evo_rope_qk_bf16 with a table for those positions followed by the indexed copy. */
+int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const float* inv_freq, float scaling,
+                                int64_t B, int64_t H, int64_t hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw, int64_t kv_sh,
+                                void* stream);
 
 /* ---- causal multi-head attention forward ------------------------------------------------------------
  * replaces flash_attn_2_cuda fwd / flash_attn_with_kvcache  [REF README.md:47-50; evo/configs/evo-1-8k-base_inference.yml:9,30]

@@ -378,3 +378,35 @@ def test_attention_decode_matches_oracle(ops, B, H, Tk, splits):
     pos = torch.tensor([Tk - 1], dtype=torch.int64, device=DEV)
     o2 = ops.attention_decode(q.to(DEV), kvd[:, :, 0], kvd[:, :, 1], pos=pos, n_splits=splits)
     assert_close_bf16(o2, ref, rl2=4e-3, atol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("positions,scaling", [([5], 1.0), ([100, 60000, 131071], 16.0), ([100, 8191, 70000], 1.0),
+                                               ([(37 * b + 5) % 300 for b in range(9)], 16.0)])
+def test_rope_append_decode_is_bitwise_table_rope_and_indexed_copy(positions, scaling):
+    """evo_rope_append_decode_bf16 (rotary at per-row positions + KV append, one launch) against the path it replaces:
+    cos/sin table for those positions -> evo_rope_qk_bf16 -> indexed copy into the cache.  Bit for bit, including angles of
+    ~1e5 rad (the range reduction of sinf / cosf)."""
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    H, hd, B = 32, 128, len(positions)
+    g = gen(B)
+    qkv = bf(torch.randn(B, 1, 3, H, hd, generator=g)).to(DEV)
+    pos = torch.tensor(positions, dtype=torch.int64, device=DEV)
+    cap = max(positions) + 1
+    kv_a = torch.zeros(B + 1, cap, 2, H, hd, dtype=torch.bfloat16, device=DEV)
+    kv_b = torch.zeros_like(kv_a)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32, device=DEV) / hd))
+    t = pos.to(torch.float32)
+    if scaling != 1.0:
+        t = t / scaling
+    fr = torch.outer(t, inv)
+    cos, sin = torch.cos(fr).to(torch.bfloat16).float().contiguous(), torch.sin(fr).to(torch.bfloat16).float().contiguous()
+    want = qkv.clone()
+    ops.rope_(want.view(1, B, 3, H, hd), cos, sin)
+    kv_b[torch.arange(B, device=DEV), pos] = want[:, 0, 1:3]
+    got = qkv.clone()
+    ops.rope_append_decode(got, kv_a[:B], pos, inv, scaling)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(kv_a, kv_b)
