@@ -22,7 +22,7 @@ def graph_time(fns):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (20 * len(fns)) * 1e3
 
-for M in (1, 2, 3, 4, 5, 6, 8):
+for M in [int(a) for a in os.environ.get("MS", "1,2,3,4,5,6,8").split(",")]:
     x = rn(M, D).bfloat16()
     sets = []
     for _ in range(6):
