@@ -152,8 +152,8 @@ __device__ __forceinline__ float gv_sumsq8(const uint4& xv, float ss) {
     for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
     return ss;
 }
-// rows of up to 512 vectors (K <= 4096; longer rows take the unstaged kernels): request everything (slices past the row end
-// re-read the lane's first vector, unused)
+// rows of up to 512 vectors (the host stages K = 4096 only; other widths take the unstaged kernels): request everything (slices
+// past the row end re-read the lane's first vector, unused)
 __device__ __forceinline__ void gv_stage_load(const uint4* xr, const uint4* scale, int nvec, int lane, uint4 (&sx)[8], uint4 (&sc)[8]) {
     const int v0 = lane < nvec ? lane : 0;
 #pragma unroll
@@ -199,7 +199,7 @@ __device__ __forceinline__ void gv_stage_finish(uint4* dst, int nvec, int lane, 
         uint4 wb[2 * GV_R];                                                                                           \
         GV_TRIP_LOAD(wb, 1)                                                                                           \
         GV_TRIP_DOT(wa, 0, XF)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0); /* (keeps the LDS reads of later trips from being hoisted: 32 M VGPRs) */  \
+        __builtin_amdgcn_sched_barrier(0); /* (trips stay in program order: requests retire in issue order) */        \
         GV_TRIP_LOAD(wa, 2)                                                                                           \
         GV_TRIP_DOT(wb, 1, XF)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -212,7 +212,8 @@ __device__ __forceinline__ void gv_stage_finish(uint4* dst, int nvec, int lane, 
 // ---- RMSNorm folded into the layer that consumes it (decode form): y = bf16(scale * x / (rms(x) + eps)) . W^T + bias.
 // Every wave first reduces sum(x^2) with the rmsnorm kernel's own lane -> element mapping and summation order (so the
 // normalised row is bit-identical to what that kernel would have stored), then streams its R rows of W while it
-// rebuilds the normalised x slice by slice in registers -- one launch instead of two per block.
+// rebuilds the normalised x slice by slice in registers -- one launch instead of two per block.  That is the STAGE = false
+// form (any K); at K = 4096 the launches take STAGE = true (above): rows normalised once into LDS, four pipelined trips.
 template <int M, int R, bool STAGE>
 __global__ __launch_bounds__(256) void gemv_norm_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
                                                         const uint4* __restrict__ w, const uint16_t* __restrict__ bias,
