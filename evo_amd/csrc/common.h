@@ -25,14 +25,34 @@ __device__ __forceinline__ uint16_t f_to_bf(float f) { return (uint16_t)(pack_bf
 // value of f after a round trip through bf16
 __device__ __forceinline__ float round_bf(float f) { return bf_lo(pack_bf2(f, 0.f)); }
 
+// Wave-wide butterfly reductions.  The four steps inside a 16-lane row are DPP operands of the add itself (no LDS traffic:
+// a __shfl_xor is a ds_bpermute, and the 4-16 reductions that end every wave of a weight-streaming launch all hit the LDS
+// pipe at the same moment); after the xor-1 and xor-2 steps the lanes of a quad agree bit for bit, so row_half_mirror /
+// row_mirror fetch the same value a xor-4 / xor-8 exchange would.  Only the two cross-row steps go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_fetch(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#define EVO_DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define EVO_DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define EVO_DPP_HALF_MIRROR 0x141
+#define EVO_DPP_MIRROR 0x140
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_fetch<EVO_DPP_XOR1>(v);
+    v += dpp_fetch<EVO_DPP_XOR2>(v);
+    v += dpp_fetch<EVO_DPP_HALF_MIRROR>(v);
+    v += dpp_fetch<EVO_DPP_MIRROR>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_fetch<EVO_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_fetch<EVO_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_fetch<EVO_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_fetch<EVO_DPP_MIRROR>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
