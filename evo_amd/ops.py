@@ -395,8 +395,6 @@ class HipOps:
                               "apply": z.numel() * 2 + y.numel() * 2 + agg.numel() * 4}
         return y, state
 
-    hyena_mfma_state = True      # the single-pass kernel takes a carry-in state and returns the end state (ABI 4)
-
     def linear_zg_ok(self, x: torch.Tensor, w: torch.Tensor) -> bool:
         """The projection of a Hyena block as a dense layer with a GROUP-MAJOR result (csrc/gemm.hip, mode 2)."""
         M, K = x.shape

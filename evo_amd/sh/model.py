@@ -498,14 +498,15 @@ class StripedHyena(nn.Module):
         """(logits [B,T,V] bf16, cache-or-None).  `padding_mask` [B,T] (1 = token, 0 = pad) is applied as upstream's
         stateless_forward applies it (block inputs / FIR output / mixer output multiplied by it); evo itself never passes
         one [REF evo/scoring.py:81; evo/generation.py:152-155] -- without it pads are ordinary tokens.  It is a scoring
-        option: with a cache (upstream's stateful_forward, which ignores the mask) it raises."""
+        option: with a cache the call is upstream's stateful_forward, which ignores the mask -- so does this (with a warning)."""
         B, T = x.shape
+        if padding_mask is not None and inference_params_dict is not None:
+            # upstream routes this call to stateful_forward, which never looks at the mask: same here (a caller written against
+            # upstream keeps working); the warning says that pads then enter the carried modal / FIR / KV state as ordinary tokens
+            import warnings
+            warnings.warn("padding_mask is ignored when inference_params_dict is given (as in upstream's stateful_forward)")
+            padding_mask = None
         if padding_mask is not None:
-            if inference_params_dict is not None:
-                # upstream honours padding_mask in stateless_forward only (stateful_forward never looks at it); a masked
-                # cached prefill would also leave padded positions inside the carried modal / FIR / KV state
-                raise ValueError("padding_mask applies to the stateless (scoring) forward; it cannot be combined with "
-                                 "inference_params_dict")
             h = self.hidden_states(x, inference_params_dict, padding_mask)
             return self.ops.linear(h, self.unembed.weight, None).view(B, T, self.vocab_size), inference_params_dict
         if T == 1 and inference_params_dict is not None and self._graph_eligible(inference_params_dict):

@@ -284,8 +284,14 @@ class SequenceParallelScorer:
         # then carry_add + apply).
         # (the choice must be the SAME on every rank -- the halo rows travel in the projection's column order -- so it is made on
         #  the shortest shard, the last one, not on this rank's own length)
+        #  the launches run per row group -- nb_max / nb_min rows -- on shards of Tl (every rank but the last) or t_min tokens:
+        #  the contract is evaluated on BOTH extremes, pure functions of (B, T, world), so every rank reaches the same verdict
         t_min = T - (self.world - 1) * Tl
-        fast = getattr(ops, "hyena_mfma", False) and hasattr(ops, "hyena_mfma_state") and m._mfma_hyena_ok(B, t_min)
+        G_ = max(1, min(self.row_groups, B))
+        nb_max, nb_min = (B + G_ - 1) // G_, max(1, B // G_)
+        fast = getattr(ops, "hyena_mfma", False) and hasattr(ops, "hyena_mfma_state") \
+            and m._mfma_hyena_ok(nb_max, Tl) and m._mfma_hyena_ok(nb_min, t_min) \
+            and m._mfma_hyena_ok(nb_max, t_min) and m._mfma_hyena_ok(nb_min, Tl)
         if fast:
             w_p, b_p, table, _, _ = m._mfma_pack(blk)
         else:

@@ -28,7 +28,9 @@ extern "C" {
  *   2: evo_embed_bf16 gained `bad_flag`; evo_hyena_seg_state / evo_hyena_apply gained `mask`;
  *      evo_unembed_logprob_bf16 and evo_hyena_mfma added.
  *   3: evo_rope_append_decode_bf16 added; the fused decode launches take up to 8 rows at K = 4096.
- *   4: evo_hyena_mfma gained the carry-in state `s0`, the end state `s_out` and `poles`; evo_hyena_mfma_state added. */
+ *   4: evo_hyena_mfma gained the carry-in state `s0`, the end state `s_out` and `poles`; evo_hyena_mfma_state added.
+ *   5: evo_mlp_gate_mfma_bf16 (GELU * gate in the dense layer's epilogue), evo_linear_zg_mfma_bf16 (group-major result) and
+ *      evo_hyena_mfma_zg (the single-pass operator on group-major z) added. */
 #define EVO_ABI_VERSION 5
 int evo_abi_version(void);
 

@@ -189,15 +189,21 @@ class RefStripedHyena:
     """Restatement of stripedhyena.model.StripedHyena.forward."""
 
     def __init__(self, cfg: RefConfig, state_dict: Dict[str, torch.Tensor], mode: str = "fp32",
-                 rotary_table_bf16: bool = True):
+                 rotary_table_bf16: bool = True, device=None):
+        """`device`: where the eager torch ops of this restatement run (default: CPU, as everywhere in the CPU suite).  The
+        GPU tests at BASELINE configs[3] / configs[4] sizes pass "cuda:0": the SAME statements then execute on torch's own
+        eager kernels (rocBLAS / rocFFT) -- still test infrastructure, no kernel of libevo_mi355x.so is involved; pinned to
+        the CPU execution by tests/test_gpu_parity_r4.py::test_oracle_on_the_gpu_is_the_cpu_oracle."""
         assert mode in ("bf16", "fp32", "fp64")
         self.cfg = cfg
         self.mode = mode
+        self.dev = torch.device("cpu" if device is None else device)
         self.rotary_table_bf16 = rotary_table_bf16
         self.act = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp64": torch.float64}[mode]
         self.hi = torch.float64 if mode == "fp64" else torch.float32   # filter / FFT / state precision
         self.w: Dict[str, torch.Tensor] = {}
         for k, v in state_dict.items():
+            v = v.to(self.dev)
             if k.endswith("poles") or k.endswith("residues"):
                 self.w[k] = v.to(self.hi)
             elif k.endswith("inv_freq"):
@@ -230,7 +236,7 @@ class RefStripedHyena:
     def compute_filter(self, pre, T: int) -> torch.Tensor:
         """upstream ParallelHyenaFilter.compute_filter: h[d,t] = Re sum_s R[d,s] * exp(t*log p[d,s])."""
         p, r = self.poles_residues(pre)
-        t = torch.arange(T, dtype=self.hi)
+        t = torch.arange(T, dtype=self.hi, device=self.dev)
         logp = torch.log(p)
         h = (r[..., None] * torch.exp(logp[..., None] * t)).real.sum(1)      # [D,T]
         return h
@@ -286,7 +292,7 @@ class RefStripedHyena:
         """S_{T-1} with S_t = p*S_{t-1} + x1v_t  (== upstream prefill_via_modal_fft)."""
         p, _ = self.poles_residues(pre)
         T = x1v.shape[-1]
-        t = torch.arange(T - 1, -1, -1, dtype=self.hi)
+        t = torch.arange(T - 1, -1, -1, dtype=self.hi, device=self.dev)
         pw = torch.exp(torch.log(p)[..., None] * t)                   # [D,S,T] p^(T-1-j)
         cdt = torch.complex128 if self.hi == torch.float64 else torch.complex64
         return torch.einsum("bdt,dst->bds", x1v.to(self.hi).to(cdt), pw.to(cdt))
@@ -310,8 +316,8 @@ class RefStripedHyena:
     # ---- attention -----------------------------------------------------------
     def rotary_table(self, T0: int, T1: int):
         hd = self.cfg.head_dim
-        inv_freq = 1.0 / (self.cfg.rotary_emb_base ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-        t = torch.arange(T0, T1, dtype=torch.float32)
+        inv_freq = 1.0 / (self.cfg.rotary_emb_base ** (torch.arange(0, hd, 2, dtype=torch.float32, device=self.dev) / hd))
+        t = torch.arange(T0, T1, dtype=torch.float32, device=self.dev)
         if self.cfg.use_interpolated_rotary_pos_emb:
             t = t / self.cfg.rotary_emb_scaling_factor
         freqs = torch.outer(t, inv_freq)
@@ -337,8 +343,8 @@ class RefStripedHyena:
         B, Tq, H, hd = q.shape
         Tk = k.shape[1]
         out = torch.empty_like(q)
-        qi = torch.arange(Tq)[:, None] + q_pos0
-        kj = torch.arange(Tk)[None, :]
+        qi = torch.arange(Tq, device=self.dev)[:, None] + q_pos0
+        kj = torch.arange(Tk, device=self.dev)[None, :]
         mask = kj > qi
         chunk = max(1, min(Tq, (1 << 24) // max(1, Tk)))
         for h in range(H):
@@ -405,7 +411,7 @@ class RefStripedHyena:
         if cache is not None:
             if i not in cache.key_value_memory_dict:
                 cache.key_value_memory_dict[i] = torch.zeros(
-                    cache.max_batch_size, cache.max_seqlen, 2, H, hd, dtype=u.dtype)
+                    cache.max_batch_size, cache.max_seqlen, 2, H, hd, dtype=u.dtype, device=u.device)
             kv = cache.key_value_memory_dict[i]
             kv[:B, off:off + T, 0] = k
             kv[:B, off:off + T, 1] = v
@@ -428,7 +434,7 @@ class RefStripedHyena:
 
     @torch.no_grad()
     def forward(self, ids: torch.Tensor, inference_params_dict=None, return_hidden: bool = False, padding_mask=None):
-        x = self.w["embedding_layer.weight"][ids.long()]
+        x = self.w["embedding_layer.weight"][ids.long().to(self.dev)]
         for i in range(self.cfg.num_layers):
             if i in self.cfg.attn_layer_idxs:
                 x = self.attn_block(x, i, inference_params_dict["mha"] if inference_params_dict else None, padding_mask)

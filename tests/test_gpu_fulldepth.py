@@ -61,28 +61,6 @@ def half_ulps(got, ref):
     return ((got - ref).abs() / (scale * 2.0 ** -9)).max().item()
 
 
-@pytest.fixture(scope="module")
-def full():
-    """One synthetic 7B state dict (built on the GPU, 12.9 GB), the HIP models of both yml configs sharing it, and
-    the fp32 / bf16-faithful CPU oracles on a host copy."""
-    from evo_amd.sh.model import StripedHyena
-    from evo_amd.synthetic import synthetic_state_dict
-    t0 = time.time()
-    m8 = StripedHyena(dict(FULL))
-    sd = synthetic_state_dict(m8, seed=0, device=DEV)
-    m8.load_state_dict(sd, strict=True)
-    m8.to_bfloat16_except_poles_residues()
-    m8 = m8.to(DEV)
-    m131 = StripedHyena(dict(FULL_131K))
-    m131.load_state_dict(m8.state_dict(), strict=True)       # adopts the same (already packed) tensors
-    m131.to_bfloat16_except_poles_residues()
-    m131 = m131.to(DEV)
-    sd_cpu = {k: v.cpu() for k, v in m8.state_dict().items()}
-    print(f"[full-depth fixture] weights in {time.time() - t0:.1f} s; host MemAvailable {_host_mem_gb():.0f} GB, "
-          f"{os.cpu_count()} cpus, torch threads {torch.get_num_threads()}")
-    return dict(m8=m8, m131=m131, sd_cpu=sd_cpu, oracles={})
-
-
 def _host_mem_gb():
     for line in open("/proc/meminfo"):
         if line.startswith("MemAvailable:"):
@@ -99,6 +77,20 @@ def oracle_for(full, cfgd, mode):
             pytest.skip(f"host has {_host_mem_gb():.0f} GB available; the {mode} full-depth oracle needs {need:.0f} GB")
         full["oracles"][mode] = R.RefStripedHyena(R.RefConfig.from_dict(cfgd), full["sd_cpu"], mode)
     o = full["oracles"][mode]
+    o.cfg = R.RefConfig.from_dict(cfgd)
+    return o
+
+
+def gpu_oracle(full, cfgd, mode):
+    """The SAME oracle class with its weights on the GPU: its statements then run on torch's eager GPU kernels (rocBLAS /
+    rocFFT; test infrastructure, nothing of libevo_mi355x.so) -- pinned to the CPU execution by
+    tests/test_gpu_parity_r4.py::test_oracle_on_the_gpu_is_the_cpu_oracle.  fp32: 26 GB of up-cast weights; bf16 aliases the
+    engine's tensors."""
+    key = "gpu_" + mode
+    if key not in full["oracles"]:
+        sd = {k: v for k, v in full["m131"].state_dict().items()}
+        full["oracles"][key] = R.RefStripedHyena(R.RefConfig.from_dict(cfgd), sd, mode, device=DEV)
+    o = full["oracles"][key]
     o.cfg = R.RefConfig.from_dict(cfgd)
     return o
 
@@ -439,30 +431,31 @@ def test_gpu_ref64_blocks_agree_with_the_cpu_oracle(full):
 
 
 # ---- (e) the score tolerance as a distribution -----------------------------------------------------------------------------
-def test_score_rel_distribution_16_sequences(full):
+def test_score_rel_distribution_64_sequences(full):
     """North-star: "logits within 1e-3 relative of the reference".  Element-wise no bf16 pipeline can meet that (a bf16 ulp is
-    3.9e-3); the quantity evo reports is the per-sequence score [REF evo/scoring.py:84-96].  16 BASELINE configs[0]
-    sequences (1 x 512 nt each, SURVEY 8(d) seeds 1234..1249) through the 32-layer engine, the fp32 oracle and the
-    eager-bf16 oracle (= the reference's own arithmetic).  Measured (tests/PARITY.md): engine mean 9.8e-4, max 3.2e-3; eager
-    bf16 mean 1.59e-3, max 4.1e-3 -- the mean sits AT the north-star's 1e-3 on these random weights (the -DHM_XLO=0 build of
-    the Hyena kernel measured 1.07e-3), so the pins were: mean <= 1.25e-3 AND <= the eager-bf16 mean, max <= the eager-bf16 max.
-    The numbers above were taken with the Hyena projections on hipBLASLt; since the end of round 3 they run on the hand-written
-    dense layer (group-major result: other summation order, same single rounding) and this test could not be re-run on that
-    routing before the round's GPU budget ended -- a statistic over 16 samples moves by +-10...20 % with the rounding noise, so the
-    absolute pins carry that margin until re-measured: mean <= 1.4e-3 AND <= the eager-bf16 mean, max <= 1.3 x the eager-bf16 max."""
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    3.9e-3); the quantity evo reports is the per-sequence score [REF evo/scoring.py:84-96].  64 BASELINE configs[0]
+    sequences (1 x 512 nt each, SURVEY 8(d) seeds 1234..1297) through the 32-layer engine, the fp32 oracle and the
+    eager-bf16 oracle (= the reference's own arithmetic).  Round 4: the oracles run on the GPU (same class, torch's eager
+    kernels; 140 s of host time per 16 sequences before), which pays for 64 samples instead of 16 -- the mean of 16 moved by
+    +-10 % between code states with identical arithmetic up to summation order (9.8e-4, 1.02e-3, 1.07e-3 in round 3).
+    Pins (tests/PARITY.md (e) has the measured values): mean over 64 <= 1.25e-3 AND <= the eager-bf16 mean, max <= the
+    eager-bf16 max; the first 16 are printed separately for continuity with round 3."""
     m = full["m8"]
-    ids = acgt_ids(16, 512)
+    ids = acgt_ids(64, 512)
     t0 = time.time()
-    ref = oracle_for(full, FULL, "fp32")(ids)[0]
-    flo = oracle_for(full, FULL, "bf16")(ids)[0]
-    t_cpu = time.time() - t0
-    got = m(ids.to(DEV))[0].cpu()
+    o32, o16 = gpu_oracle(full, FULL, "fp32"), gpu_oracle(full, FULL, "bf16")
+    ref = torch.cat([o32(ids[i:i + 16])[0].float().cpu() for i in range(0, 64, 16)])
+    flo = torch.cat([o16(ids[i:i + 16])[0].float().cpu() for i in range(0, 64, 16)])
+    torch.cuda.synchronize()
+    t_or = time.time() - t0
+    got = torch.cat([m(ids[i:i + 16].to(DEV))[0].cpu() for i in range(0, 64, 16)])
     s_ref, s_flo, s_got = score_of(ref, ids), score_of(flo, ids), score_of(got, ids)
     rel = ((s_got - s_ref).abs() / s_ref.abs())
     rel_flo = ((s_flo - s_ref).abs() / s_ref.abs())
-    print(f"[score distribution] 16 x 513 tokens, oracles {t_cpu:.0f} s: engine score_rel mean {rel.mean():.2e} max {rel.max():.2e} "
-          f"median {rel.median():.2e}; eager-bf16 oracle mean {rel_flo.mean():.2e} max {rel_flo.max():.2e}")
+    print(f"[score distribution] 64 x 513 tokens, oracles (on the GPU) {t_or:.0f} s: engine score_rel mean {rel.mean():.3e} max {rel.max():.2e} "
+          f"median {rel.median():.2e}; eager-bf16 oracle mean {rel_flo.mean():.3e} max {rel_flo.max():.2e} median {rel_flo.median():.2e}")
+    print(f"[score distribution] first 16 (the round-3 sample): engine mean {rel[:16].mean():.3e} max {rel[:16].max():.2e}; "
+          f"eager-bf16 mean {rel_flo[:16].mean():.3e} max {rel_flo[:16].max():.2e}")
     print("[score distribution] engine:", " ".join(f"{x:.1e}" for x in rel.tolist()))
-    assert rel.mean().item() <= 1.4e-3 and rel.mean().item() <= rel_flo.mean().item()
-    assert rel.max().item() <= 1.3 * rel_flo.max().item()
+    assert rel.mean().item() <= 1.25e-3 and rel.mean().item() <= rel_flo.mean().item()
+    assert rel.max().item() <= rel_flo.max().item()

@@ -1,0 +1,309 @@
+"""GPU (-m gpu): model-level parity of BASELINE configs[4] and configs[3] at the REAL dimensions (D = 4096, H = 32,
+inner 10928; 32 layers for configs[4]) -- the two configs that until round 4 were only checked on toy models.
+
+ (a) configs[4], "evo-1-131k-base generation: 8,192-nt prompt -> new tokens, recurrent Hyena state + KV cache"
+     [REF evo/generation.py:105-155 with evo-1-131k-base_inference.yml]: the 32-layer engine prefills the 8,192-token prompt
+     into its caches, then decodes greedily -- first step eager, the rest hipGraph replays.  Checked against the oracle's
+     CACHED path (oracle/stripedhyena_ref.py: hyena_filter_parallel(want_state) / prefill_state_recurrence,
+     hyena_filter_step, the KV-cache branch of attn_block) in fp32:
+       * graph-replayed steps == eager steps, bit for bit, at 7B dimensions;
+       * every block TEACHER-FORCED: the engine's residual stream entering block i (prompt pass and every decode step) is
+         fed to the oracle's block i together with the ORACLE's cache -- block outputs (PIN_BLOCK), the modal end state,
+         the FIR history and the K/V rows the prompt pass leaves behind, then every decode step's block outputs;
+       * end to end on the oracle's own cached path, the oracle fed the ENGINE's tokens (one flipped argmax does not
+         cascade): prompt logits, per-step logits, argmax agreement -- beside the eager-bf16 restatement of the reference.
+ (b) configs[3], "batch x 131,072 nt, sequence-parallel across 8 GPUs": eight virtual ranks (threads sharing the one GPU,
+     the `_ThreadComm` of tests/test_gpu_model.py) run `SequenceParallelScorer` on 16,385-token shards of 2 x 131,073 tokens
+     at D = 4096 through 4 layers (Hyena, attention, Hyena, Hyena): carry-in state from up to 7 predecessors with pole powers
+     p^(16385 k), the FIR halo, Ulysses over 4 heads x 131,073 keys.  Against the unsharded HIP forward, and shard 7's
+     layer-0 Hyena output against the fp64 FFT long convolution over the WHOLE sequence (tests/gpu_ref64.py).
+ (c) the oracle executed by torch on the GPU (what (a) uses at 8,192 tokens) is pinned to its CPU execution.
+"""
+import math
+import threading
+import time
+
+import pytest
+import torch
+
+from conftest import FULL_131K
+from gpu_ref64 import gpu_fft_hyena
+from oracle import stripedhyena_ref as R
+from test_gpu_fulldepth import PIN_BLOCK, acgt_ids, gpu_oracle, half_ulps, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gpu_oracle(full, mode):
+    """cfg = the 131k yml with room in the KV cache for the decode steps."""
+    return gpu_oracle(full, dict(FULL_131K, max_seqlen=8192 + 256), mode)
+
+
+def test_oracle_on_the_gpu_is_the_cpu_oracle(full):
+    """(c) the same oracle statements executed by torch's eager GPU kernels (fp32 rocBLAS / rocFFT) and on the CPU: the
+    full 32-layer forward on a BASELINE configs[0] input agrees to fp32 rounding through 32 layers, cached path included
+    (prefill of 400 tokens + 3 recurrent steps)."""
+    from test_gpu_fulldepth import oracle_for
+    ids = acgt_ids(1, 512)
+    og = _gpu_oracle(full, "fp32")
+    oc = oracle_for(full, dict(FULL_131K, max_seqlen=8192 + 256), "fp32")
+    a = og(ids)[0].cpu()
+    b = oc(ids)[0]
+    d = rel_l2(a, b)
+    cg, cc = og.initialize_inference_params(), oc.initialize_inference_params()
+    lg, _ = og(ids[:, :400], cg)
+    lc, _ = oc(ids[:, :400], cc)
+    worst = rel_l2(lg.cpu(), lc)
+    for t in range(400, 403):
+        for c in (cg, cc):
+            c["mha"].seqlen_offset = c["hyena"].seqlen_offset = t
+        worst = max(worst, rel_l2(og(ids[:, t:t + 1], cg)[0].cpu(), oc(ids[:, t:t + 1], cc)[0]))
+    print(f"[oracle gpu vs cpu] 32-layer fp32 forward on 513 tokens: logits rel-L2 {d:.2e}; cached path (400 + 3 steps) {worst:.2e}")
+    assert d < 2e-4 and worst < 2e-4
+
+
+def _engine_generate(m, prompt, n_new, graph, forced=None, taps=False):
+    """The token loop of evo_amd.generation.Generator.generate (greedy) written out, so that the residual stream can be
+    tapped: returns (tokens [n_new], logits of the prompt pass [P,V], step logits [n_new,V], cache, taps per forward)."""
+    m.decode_graph = graph
+    m._dgraph = None
+    m._dgraph_warm = None
+    c = m.initialize_inference_params()
+    c["mha"].max_batch_size = c["hyena"].max_batch_size = 1
+    P = prompt.shape[1]
+    all_taps, toks, step_logits = [], [], []
+    x = prompt
+    prompt_logits = None
+    for i in range(n_new):
+        if i > 0:
+            c["mha"].seqlen_offset = c["hyena"].seqlen_offset = P + i - 1
+        if taps:
+            m.block_taps = []
+        try:
+            with torch.inference_mode():
+                logits, c = m(x, c)
+        finally:
+            if taps:
+                all_taps.append(m.block_taps)
+                m.block_taps = None
+        if i == 0:
+            prompt_logits = logits[0].float()
+        last = logits[:, -1].float()
+        step_logits.append(last[0])
+        tok = last.argmax(-1) if forced is None else forced[i:i + 1]
+        toks.append(tok)
+        x = tok[:, None]
+    return torch.cat(toks), prompt_logits, torch.stack(step_logits), c, all_taps
+
+
+def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
+    m = full["m131"]
+    P, N = 8192, 34                                           # prompt pass + 33 decode forwards (1 eager warm-up, 32 replays)
+    D = 4096
+    prompt = acgt_ids(1, P)[:, 1:].to(DEV)                     # generation prompts carry no BOS [REF evo/generation.py:64-73]
+    assert prompt.shape == (1, P)
+    keep = m.decode_graph
+    replays0 = getattr(m, "decode_graph_replays", 0)
+    try:
+        toks, pl_g, sl_g, cache_g, _ = _engine_generate(m, prompt, N, graph=True)
+        replays = getattr(m, "decode_graph_replays", 0) - replays0
+        assert m._dgraph is not None and m.decode_graph, "the hipGraph decode step did not engage"
+        m.release_decode_graph()
+        toks_e, pl_e, sl_e, cache, taps = _engine_generate(m, prompt, N, graph=False, forced=toks, taps=True)
+    finally:
+        m.decode_graph = keep
+        m.release_decode_graph()
+    assert replays >= 32
+    assert torch.equal(toks, toks_e)
+    assert torch.equal(pl_g, pl_e) and torch.equal(sl_g, sl_e), "graph-replayed decode steps differ from eager steps"
+    assert len(taps) == N and all(len(t) == 33 for t in taps)
+    attn_idx = set(FULL_131K["attn_layer_idxs"])
+    o = _gpu_oracle(full, "fp32")
+    oc = o.initialize_inference_params()
+
+    # ---- every block teacher-forced, WITH the oracle's caches: the prompt pass, then every decode step -------------------
+    t0 = time.time()
+    worst = {"hyena": [0.0, 0.0, 0.0], "attn": [0.0, 0.0, 0.0]}
+    state_rel = fir_max = kv_rel = 0.0
+    bad = []                                                   # (every measurement is printed before anything is asserted)
+    for i in range(32):
+        kind = "attn" if i in attn_idx else "hyena"
+        u = taps[0][i].float().view(1, P, D)
+        ref = o.attn_block(u, i, oc["mha"]) if kind == "attn" else o.hyena_block(u, i, oc["hyena"])
+        got = taps[0][i + 1].float().view(1, P, D)
+        err, hu, upd = rel_l2(got, ref), half_ulps(got, ref), rel_l2(got - u, ref - u)
+        worst[kind] = [max(a, b) for a, b in zip(worst[kind], (err, hu, upd))]
+        if not (err <= PIN_BLOCK[kind] and hu <= PIN_BLOCK["hulp"] and upd <= PIN_BLOCK["upd"]):
+            bad.append(("prompt", i, kind, err, hu, upd))
+        if kind == "hyena":                                    # what the prompt pass leaves in the caches (same block input)
+            se, sr = cache["hyena"].state_dict[i].to(torch.complex128), oc["hyena"].state_dict[i].to(torch.complex128)
+            state_rel = max(state_rel, ((se - sr).abs().max() / sr.abs().max()).item())
+            fe, fr = cache["hyena"].fir_state_dict[i].double(), oc["hyena"].fir_state_dict[i].double()
+            fir_max = max(fir_max, ((fe - fr).abs() / (fr.abs() * 2.0 ** -8 + fr.abs().max() * 2e-3)).max().item())
+        else:
+            ke = cache["mha"].key_value_memory_dict[i][:1, :P].double()
+            kr = oc["mha"].key_value_memory_dict[i][:1, :P].double()
+            kv_rel = max(kv_rel, ((ke - kr).norm() / kr.norm()).item())
+        del ref, got, u
+    print(f"[configs4 prompt pass, 8192 tokens, teacher-forced + cached] worst Hyena block: output rel-L2 {worst['hyena'][0]:.3e}, "
+          f"half-ulps {worst['hyena'][1]:.1f}, update {worst['hyena'][2]:.3e}; attention: {worst['attn'][0]:.3e}, {worst['attn'][1]:.1f}, "
+          f"{worst['attn'][2]:.3e}; modal end state rel {state_rel:.2e}, FIR history worst / (2^-8|ref| + 2e-3 max) {fir_max:.2f}, "
+          f"K/V rows rel-L2 {kv_rel:.2e}  ({time.time() - t0:.1f} s)")
+    # the end state sums 8,192 bf16-rounded inputs: the reference's own eager-bf16 arithmetic sits at 2.8e-3 (tests/PARITY.md (e))
+    t0 = time.time()
+    wstep = {"hyena": [0.0, 0.0, 0.0], "attn": [0.0, 0.0, 0.0]}
+    for s in range(1, N):
+        oc["mha"].seqlen_offset = oc["hyena"].seqlen_offset = P + s - 1
+        for i in range(32):
+            kind = "attn" if i in attn_idx else "hyena"
+            u = taps[s][i].float().view(1, 1, D)
+            ref = o.attn_block(u, i, oc["mha"]) if kind == "attn" else o.hyena_block(u, i, oc["hyena"])
+            got = taps[s][i + 1].float().view(1, 1, D)
+            err, hu, upd = rel_l2(got, ref), half_ulps(got, ref), rel_l2(got - u, ref - u)
+            wstep[kind] = [max(a, b) for a, b in zip(wstep[kind], (err, hu, upd))]
+            if not (err <= PIN_BLOCK[kind] and hu <= PIN_BLOCK["hulp"] and upd <= 1.5 * PIN_BLOCK["upd"]):
+                bad.append(("step", s, i, kind, err, hu, upd))
+    print(f"[configs4 {N - 1} decode steps x 32 blocks, teacher-forced, oracle step_fir / step_iir / KV cache] worst Hyena block: "
+          f"output rel-L2 {wstep['hyena'][0]:.3e}, half-ulps {wstep['hyena'][1]:.1f}, update {wstep['hyena'][2]:.3e}; attention: "
+          f"{wstep['attn'][0]:.3e}, {wstep['attn'][1]:.1f}, {wstep['attn'][2]:.3e}  ({time.time() - t0:.1f} s)")
+    del taps, oc
+    assert not bad, bad[:12]
+    assert state_rel <= 6e-3 and fir_max <= 1.0 and kv_rel <= 4e-3, (state_rel, fir_max, kv_rel)
+
+    # ---- end to end: the oracle's own cached path, fed the engine's tokens; the eager-bf16 restatement beside it ---------------
+    def oracle_run(orc):
+        c = orc.initialize_inference_params()
+        lp = orc(prompt, c)[0][0].float()
+        steps = [lp[-1]]
+        for s in range(1, N):
+            c["mha"].seqlen_offset = c["hyena"].seqlen_offset = P + s - 1
+            steps.append(orc(toks[None, s - 1:s], c)[0][0, 0].float())
+        return lp, torch.stack(steps)
+    t0 = time.time()
+    rp, rs = oracle_run(o)
+    fp_, fs = oracle_run(_gpu_oracle(full, "bf16"))
+    e_p, f_p = rel_l2(pl_g, rp), rel_l2(fp_, rp)
+    e_s, f_s = rel_l2(sl_g, rs), rel_l2(fs, rs)
+    agree = (sl_g.argmax(-1) == rs.argmax(-1)).float().mean().item()
+    agree_f = (fs.argmax(-1) == rs.argmax(-1)).float().mean().item()
+    lsm = lambda x: torch.log_softmax(x.double(), -1).gather(-1, toks[:, None].long()).mean().item()   # noqa: E731
+    sc_e, sc_r, sc_f = lsm(sl_g), lsm(rs), lsm(fs)
+    print(f"[configs4 end to end vs the fp32 oracle's cached path, oracle fed the engine's tokens] prompt logits rel-L2 {e_p:.3e} "
+          f"(eager-bf16 oracle {f_p:.3e}); {N} step logits rel-L2 {e_s:.3e} (eager-bf16 {f_s:.3e}); tokens_agree {agree:.2f} "
+          f"(eager-bf16 {agree_f:.2f}); mean log-prob of the generated tokens engine {sc_e:.5f} fp32 {sc_r:.5f} eager-bf16 {sc_f:.5f}  "
+          f"({time.time() - t0:.1f} s)")
+    assert e_p <= 2.0e-1 and e_p <= 1.1 * f_p                  # (same end-to-end pins as the configs[1] prefix test)
+    assert e_s <= 2.5e-1 and e_s <= 1.25 * f_s
+    assert abs(sc_e - sc_r) / abs(sc_r) <= max(3e-2, 1.5 * abs(sc_f - sc_r) / abs(sc_r))
+
+
+# ---- (b) configs[3]: eight virtual ranks on 16,385-token shards at D = 4096 ------------------------------------------------
+SP4 = dict(vocab_size=512, hidden_size=4096, num_layers=4, attn_layer_idxs=[1], num_attention_heads=32,
+           use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+
+
+def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
+    from evo_amd.scoring import logits_to_logprobs
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.sp import SequenceParallelScorer
+    from evo_amd.synthetic import synthetic_state_dict
+    from test_gpu_model import _ThreadComm
+    world, B, T, D, H = 8, 2, 131073, 4096, 32
+    m = StripedHyena(dict(SP4))
+    m.load_state_dict(synthetic_state_dict(m, seed=3, device=DEV), strict=True)
+    m.to_bfloat16_except_poles_residues()
+    m = m.to(DEV)
+    m._pack()
+    ids = acgt_ids(B, T - 1).to(DEV)
+    with torch.inference_mode():
+        full_logits = m(ids)[0]
+    assert full_logits.shape == (B, T, 512) and torch.isfinite(full_logits.float()).all()
+
+    ops = m.ops
+    comm = _ThreadComm(world)
+    rec = {r: [] for r in range(world)}                       # per rank: (z as the kernel got it, z_halo, s0, y) of Hyena layer 0
+    real_prefill = ops.hyena_mfma_prefill
+
+    def spy(z, *a, **kw):
+        y = real_prefill(z, *a, **kw)
+        r = comm.local.rank
+        if len(rec[r]) < 2:                                   # layer 0 = the first two calls of a rank (two row groups of one row)
+            halo = a[5] if len(a) > 5 else kw.get("z_halo")
+            rec[r].append((z.clone(), None if halo is None else halo.clone(), kw.get("s0"), (y[0] if isinstance(y, tuple) else y).clone(),
+                           kw.get("zg_shape")))
+        return y
+
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm.bind(r)
+            sp = SequenceParallelScorer(m, r, world, comm=comm)
+            with torch.inference_mode():
+                lg = sp.forward_local(ids)
+                lp = sp.score_logprobs(ids)
+            outs[r] = (sp.shard(T), lg, lp)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            comm.bar.abort()
+
+    ops.hyena_mfma_prefill = spy
+    try:
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(900) for t in th]
+    finally:
+        del ops.hyena_mfma_prefill                             # (the instance attribute shadowed the method)
+    assert not errs, errs
+    Tl = outs[0][0][0]
+    assert Tl == 16385 and [o[0][2] - o[0][1] for o in outs] == [16385] * 7 + [16378]
+    sharded = torch.cat([o[1] for o in outs], 1)
+    assert sharded.shape == full_logits.shape
+    err = rel_l2(sharded, full_logits)
+    worst_shard = max(rel_l2(o[1], full_logits[:, o[0][1]:o[0][2]]) for o in outs)
+    lp = torch.cat([o[2] for o in outs], 1).double().cpu()
+    want = logits_to_logprobs(full_logits.float().cpu(), ids.cpu(), trim_bos=True).double()
+    assert lp.shape == want.shape
+    dlp, dscore = (lp - want).abs().mean().item(), (abs(lp.mean() - want.mean()) / abs(want.mean())).item()
+    print(f"[configs3, 8 virtual ranks x 16,385 tokens, D = 4096, 4 layers] sharded vs unsharded HIP forward: logits rel-L2 {err:.3e} "
+          f"(worst shard {worst_shard:.3e}), mean |d logprob| {dlp:.2e}, score rel {dscore:.2e}")
+    assert err < 8e-3 and worst_shard < 1.2e-2                 # bf16 noise of another tiling through 4 blocks (two-process test: 8e-3)
+    assert dlp < 5e-2 and dscore < 3e-3
+
+    # ---- shard 7's Hyena output of layer 0 (carry from 7 predecessors) vs the fp64 FFT long convolution over the WHOLE sequence
+    assert all(len(rec[r]) == 2 for r in range(world)), {r: len(v) for r, v in rec.items()}
+    _, _, _, perm, inv = m._mfma_pack(m.blocks[0])
+    f = m.blocks[0].filter
+
+    def token_major(z, zg_shape, nrows):
+        """what the kernel was handed -> [rows, Tloc, 3 D] in the REFERENCE column order"""
+        if zg_shape is not None:                               # group-major [D/16][rows * Tloc][48]
+            nb, tl = zg_shape
+            z = z.view(D // 16, nb, tl, 48).permute(1, 2, 0, 3).reshape(nb, tl, 3 * D)
+        return z[..., inv]
+
+    heads = [0, 13, 31]
+    cols = torch.cat([torch.arange(h * 384, (h + 1) * 384) for h in heads]).to(DEV)
+    chans = torch.cat([torch.arange(h * 128, (h + 1) * 128) for h in heads]).to(DEV)
+    assert rec[7][0][2] is not None and rec[0][0][2] is None   # rank 7 was seeded with a carried state, rank 0 was not
+    t0 = time.time()
+    worst_rl2 = worst_ex = 0.0
+    for b in range(B):
+        zfull = torch.cat([token_major(rec[r][b][0], rec[r][b][4], 1)[0][:, cols] for r in range(world)], 0)     # [T, 3 * 384]
+        assert zfull.shape == (T, 3 * 384)
+        ry, _ = gpu_fft_hyena(zfull[None], f._fir_w[cols], f.short_filter_bias.data[cols], f._poles[chans], f._residues[chans],
+                              f.D.data[chans], len(heads), want_state=False)
+        got = rec[7][b][3].view(-1, D)[:, chans].double()
+        ref = ry[0, 7 * Tl:]
+        assert got.shape == ref.shape == (16378, 384)
+        e = (got - ref).abs()
+        bound = ref.abs() * 2 ** -8 + float(ry.abs().max()) * 2e-3
+        worst_ex = max(worst_ex, (e - bound).max().item())
+        worst_rl2 = max(worst_rl2, ((got - ref).norm() / ref.norm()).item())
+        del ry, zfull
+    print(f"[configs3 shard 7, layer 0] Hyena output (carry-in from 7 predecessors, halo from rank 6) vs the fp64 FFT long convolution "
+          f"over all 131,073 tokens, heads {heads}: rel-L2 {worst_rl2:.3e}, worst excess over the bf16 bound {worst_ex:.3e} "
+          f"({time.time() - t0:.1f} s)")
+    assert worst_ex <= 0.0 and worst_rl2 < 2e-3

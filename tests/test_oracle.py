@@ -139,3 +139,23 @@ def test_padding_mask_host_path_matches_oracle_and_is_inert_when_all_ones():
     assert (got[1, :6] - full[1, :6]).abs().max() < 1e-9
     with pytest.raises(ValueError):
         m(ids, padding_mask=torch.ones(2, 18))
+
+
+def test_padding_mask_with_a_cache_is_ignored_like_upstream_stateful_forward():
+    """upstream routes model(x, inference_params_dict, padding_mask) to stateful_forward, which never looks at the
+    mask; round 3 raised here.  Now: a warning, and exactly the result of the same call without the mask."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from golden_common import tiny_model
+    m = tiny_model()
+    ids = torch.randint(0, 512, (2, 11), generator=torch.Generator().manual_seed(5))
+    mask = torch.ones(2, 11, dtype=torch.bool)
+    mask[0, 7:] = False
+    c0 = m.initialize_inference_params()
+    c0["mha"].max_batch_size = c0["hyena"].max_batch_size = 2
+    want = m(ids, c0)[0]
+    c1 = m.initialize_inference_params()
+    c1["mha"].max_batch_size = c1["hyena"].max_batch_size = 2
+    with pytest.warns(UserWarning, match="padding_mask is ignored"):
+        got = m(ids, c1, padding_mask=mask)[0]
+    assert torch.equal(got, want)

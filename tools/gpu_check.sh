@@ -5,7 +5,7 @@
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 R=$PWD
 O=gpurun_out/check; mkdir -p $O
-export EVO_AMD_NO_REBUILD=1
+# (no EVO_AMD_NO_REBUILD here: ops.py rebuilds a library that is older than its sources, so the checks run the HEAD kernels)
 if [ "$1" != "notests" ]; then
 timeout 2400 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed" $O/gpu_tests.log | tail -2
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log

@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 R=$PWD
 O=gpurun_out/final; mkdir -p $O
-export EVO_AMD_NO_REBUILD=1
+# (no EVO_AMD_NO_REBUILD here: ops.py rebuilds a library that is older than its sources, so the checks run the HEAD kernels)
 timeout 900 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; grep -E "^E  |FAILED|passed|failed" $O/gpu_tests.log | tail -6
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.json
