@@ -1,0 +1,534 @@
+// Hyena operator, single pass over GROUP-MAJOR z, CHANNEL-STATIONARY waves (gfx950).  Round 4.
+//
+// Same operator and the same blocked arithmetic as csrc/hyena_mfma.hip -- FIR(k = 3) + bias on x2 | x1 | v, x = x1 * v, long
+// convolution with h_k = Re sum_s R_s p_s^k as  y0 = T0 . X,  E = W . X  (v_mfma_f32_16x16x32_bf16, operands split into bf16
+// terms), a Kogge-Stone scan of the 16 block aggregates (fp32 VALU, DPP row shifts),  y = y0 + G . S,  (y + x1v D) * x2 --
+// but a different division of labour.  hyena_mfma.hip has every wave PRODUCE 64 steps of all 16 channels (FIR, x1 * v, bf16
+// planes in LDS), then CONSUME two channels (planes back from LDS into the matrix cores), then gate and store a third time
+// slice: three LDS round trips per value (planes, parked x2, fp32 y^T) and an 8 x 8 transposition by v_perm; measured
+// issue-bound (profiles/r03_hyena_mfma_notes.txt: ~590 instructions per wave and tile, ~400 KB through the LDS pipe per tile
+// and CU, 0.44-0.49 of HBM).  Here a wave OWNS its channels for the whole tile:
+//
+//   workgroup = one 16-channel group of one batch row stream, HC_NW waves; wave = HC_CPW = 16 / HC_NW channels (4 | 2);
+//   lane (la = lane & 15, lq = lane >> 4) = block la (32 steps), steps 8 lq .. 8 lq + 7 of it -- which is exactly the lane
+//   that holds those steps in the B operand of the 16x16x32 MFMA (k = 8 lq + j, n = la).  So the FIR outputs of a lane,
+//   x = x1 * v split into bf16 hi + lo, ARE its B-operand registers: no planes, no transposition.  The D operand of
+//   T0 . X has rows (mt, 4 lq + r): with the ROWS of T0 and G permuted at load time (logical row 16 mt + 4 q + r <- step
+//   8 q + 4 mt + r) a lane's eight accumulators are the outputs of its own eight steps, whose FIR'd x2 it also holds: the
+//   gate is in-lane, no parked x2, no fp32 y^T.  What goes through LDS: the z window (DMA in, one 8-byte read per row,
+//   signal and 4 channels) and the bf16 outputs (32-byte rows staged for 16-byte stores).
+//
+//   window  [2 buffers][16 blocks x (32 rows x 96 B + 16 B pad)]: tile k + 1 is fetched (buffer_load ... lds, bounded
+//           descriptor: rows past the end of the stream read as zeros) while tile k is computed; the pad puts the 16 blocks
+//           a ds_read_b64 touches on 16 distinct bank quads (a column read of 8 B out of 16-byte DMA granules cannot do
+//           better than 2-way: 4 LDS cycles per read).  The two rows before a tile (FIR history) are kept by the lane that
+//           read them last (lane 63: rows 510, 511) in a 2 x 192 B halo slot.
+//   ONE barrier per tile: it publishes window(k) (every wave waited for its own DMA pieces) and staging(k - 1).
+//
+// Per tile and wave (HC_CPW = 4, X_lo kept): ~720 VALU, 52 MFMA, 30 + 20 LDS reads, 8 LDS writes, 13 DMA pieces, 4 stores
+// -- against 2 x 590 instructions per SIMD in hyena_mfma.hip; LDS traffic 1.2 k instead of 2.9 k+ cycles per tile.
+// Entry point and reference citation: include/evo_mi355x.h (evo_hyena_cs_zg).
+#include "common.h"
+#include "../../include/evo_mi355x.h"
+
+#ifndef HC_XLO
+#define HC_XLO 1                            // 1: X = x1 * v as bf16 hi + lo; 0: one bf16 term (where the reference rounds it)
+#endif
+#ifndef HC_NW
+#define HC_NW 8                             // waves per workgroup: 8 (two per SIMD, 2 channels each) | 4 (one per SIMD, 4 channels each)
+#endif
+#define HC_CH 16
+#define HC_CPW (HC_CH / HC_NW)              // channels per wave: 4 | 2
+#define HC_NPAIR (HC_CPW / 2)               // channel pairs per wave: 2 | 1
+#define HC_THREADS (64 * HC_NW)
+#define HC_TT 512                           // steps per tile = 16 blocks of 32
+#define HC_ROWB 96                          // bytes of a z row of one group: x2 16 | x1 16 | v 16 bf16
+#define HC_BLKB (32 * HC_ROWB + 16)         // LDS image of a block: 32 rows + 16 B pad = 3,088
+#define HC_NPIECE 49                        // 1 KiB DMA pieces per window (16 x 3,088 = 49,408 B -> 48.25)
+#define HC_WINB (HC_NPIECE * 1024)          // 50,176
+#define HC_PPW ((HC_NPIECE + HC_NW - 1) / HC_NW)        // DMA pieces per wave and tile: 13 | 7
+#define HC_STGB (HC_TT * 32 + 16 * 16)      // staged outputs: 512 rows of 32 B, 16 B pad after every 32 rows = 16,640
+#define HC_RW (HC_TT / HC_NW)               // rows a wave stores: 128 | 64
+#define HC_NST (HC_RW / 32)                 // 16-byte stores per lane and tile: 4 | 2
+#define HC_OFF_WIN 0
+#define HC_OFF_STG (2 * HC_WINB)
+#define HC_OFF_HALO (HC_OFF_STG + 2 * HC_STGB)          // [2 parities][2 rows][96 B]
+#define HC_OFF_PW (HC_OFF_HALO + 2 * 2 * HC_ROWB)       // scan powers [16 ch][4 k][16 components] f32 = 4 KiB
+#define HC_OFF_FW (HC_OFF_PW + HC_CH * 4 * 16 * 4)      // FIR taps + bias, fp32 pairs: [8 pairs][3 signals][4] x 8 B = 768 B
+#define HC_OFF_XS (HC_OFF_FW + 768)                     // end-state scratch: per wave the hi | lo planes of one channel (2 KiB)
+#define HC_LDS (HC_OFF_XS + HC_NW * 2048)
+static_assert(HC_LDS <= 160 * 1024, "LDS");
+#define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
+
+typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t hc_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t hc_u32x2 __attribute__((ext_vector_type(2)));
+typedef int hc_srd __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x2_t hc_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t hc_bf2(uint32_t w) { f32x2_t r = {bf_lo(w), bf_hi(w)}; return r; }
+__device__ __forceinline__ hc_u32x4 hc_u4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { hc_u32x4 r = {a, b, c, d}; return r; }
+template <int D_>
+__device__ __forceinline__ float hc_shr(float v) {          // value of lane (a - D_) of the 16-lane row, 0 where a < D_
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + D_, 0xf, 0xf, true));
+}
+
+// With two waves per SIMD sharing the matrix pipe hipcc under-pads MFMA -> consumer distances (hyena_mfma.hip, round 2): the
+// bursts are fenced there.  One wave per SIMD (HC_NW = 4) is the case its hazard recogniser models: no fences.
+#if HC_NW == 8
+#define HC_FENCE_NOP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HC_FENCE_NOP() do { } while (0)
+#endif
+
+struct hc_false { static constexpr bool value = false; };
+struct hc_true { static constexpr bool value = true; };
+
+struct HcArgs {
+    const unsigned char* z; const uint32_t* z_halo; const uint16_t* fir_w; const uint16_t* fir_b;
+    const uint32_t* tab; unsigned char* y; const float* s0; float* s_out; const float* poles;
+    int B; int T; int D; int n_tiles; int n_groups; int nb_split;
+    int64_t z_group_rows;                                   // rows between two groups' streams in z (>= B * T)
+    int64_t y_rowbytes;
+};
+
+// words of a channel's table kept in registers: T0 [mt 2][hi, lo][4] = 0..15, W [hi, mid][4] = 16..23, G [mt 2][4] = 24..31
+#define HC_NTB 32
+
+// SO = "state only": the same walk, nothing written but the end state (stage 1 of a sequence-parallel shard).
+// HALF: with HC_CPW = 2 the wave takes dword HALF of every 8-byte (4-channel) window read; unused with HC_CPW = 4.
+// WS = "want state": the instantiation that finishes the state after the last token (`s_out`); scoring launches carry no trace of it.
+template <bool SO, bool WS, int HALF>
+__device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int la = lane & 15, lq = lane >> 4;
+    const int q4 = HC_CPW == 4 ? wave : wave >> 1;          // the 4-channel quad of the group this wave reads
+    const int ch0 = 4 * q4 + (HC_CPW == 4 ? 0 : 2 * HALF);   // first channel of the wave within the group
+    int b0, cg;
+    {
+        const int bid = blockIdx.x, total = gridDim.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int per_xcd = total >> 3;                     // host guarantees total % 8 == 0
+        const int s = xcd * per_xcd + slot;                 // contiguous stream ids per XCD: the four groups of a y line together
+        b0 = s / a.n_groups;
+        cg = s - b0 * a.n_groups;
+    }
+    const int h = cg >> 3, cw0 = (cg & 7) * HC_CH;
+    const int d0 = h * 128 + cw0;                           // first output channel of the group
+    const int Ti = a.T;
+    const int n_rows = (a.B - b0 + a.nb_split - 1) / a.nb_split;
+    const int n_steps = n_rows * a.n_tiles;
+    struct Cur { int b, tile; };
+    auto advance = [&](Cur& c) { if (++c.tile == a.n_tiles) { c.tile = 0; c.b += a.nb_split; } };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- constants: FIR taps / bias of the wave's channel pairs (registers), scan powers (LDS), MFMA operand tables (registers)
+    // FIR taps + bias as fp32 pairs in LDS, [wave][pair][signal x2, x1, v][tap 0, 1, 2, bias] (wave-uniform values: left to the
+    // compiler they go to SGPRs, 48 per wave, which spill and bind the one-scalar-operand limit of the packed FMAs)
+    f32x2_t* fwl = (f32x2_t*)(smem + HC_OFF_FW) + wave * (HC_NPAIR * 12);
+    if (lane < HC_NPAIR * 12) {
+        const int pp = lane / 12, rem = lane - 12 * pp, g = rem >> 2, k = rem & 3;
+        const int c = h * 384 + g * 128 + cw0 + ch0 + 2 * pp;
+        f32x2_t v;
+        if (k < 3) { v[0] = bf_to_f(a.fir_w[c * 3 + k]); v[1] = bf_to_f(a.fir_w[(c + 1) * 3 + k]); }
+        else { v[0] = bf_to_f(a.fir_b[c]); v[1] = bf_to_f(a.fir_b[c + 1]); }
+        fwl[lane] = v;
+    }
+    float* pwl = (float*)(smem + HC_OFF_PW);                 // [ch][k][16] f32
+    if (tid < HC_CH * 16) {
+        const int c = tid >> 4, m = tid & 15;               // component m = 4 q + r sits in table word 36 + 4 k + r of the lanes with lq = q
+        const uint32_t* tp = a.tab + ((int64_t)(d0 + c) * HC_TABW) * 64 + (m >> 2) * 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pwl[(c * 4 + k) * 16 + m] = __builtin_bit_cast(float, tp[(36 + 4 * k + (m & 3)) * 64]);
+    }
+    uint32_t tb[HC_CPW][HC_NTB];
+    {
+        // row permutation of T0 and G: logical row 16 mt + la (la = 4 q + r) of this kernel is step 8 q + 4 mt + r of the block,
+        // i.e. row 8 (q & 1) + 4 mt + r of the table's M tile q >> 1 -- a lane's accumulators (rows 4 lq + r of both M tiles) are
+        // then its own eight steps 8 lq + 4 mt + r.  W (rows = state components) and the K order stay as the table has them.
+        const int q = la >> 2, r = la & 3;
+#pragma unroll
+        for (int cc = 0; cc < HC_CPW; ++cc) {
+            const uint32_t* tp = a.tab + ((int64_t)(d0 + ch0 + cc) * HC_TABW) * 64;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int src_mt = q >> 1, src_lane = (8 * (q & 1) + 4 * mt + r) + 16 * lq;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) tb[cc][8 * mt + 4 * sp + w] = tp[((src_mt * 2 + sp) * 4 + w) * 64 + src_lane];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) tb[cc][24 + 4 * mt + w] = tp[(28 + 4 * src_mt + w) * 64 + src_lane];
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tb[cc][16 + w] = tp[(16 + w) * 64 + lane];
+        }
+        // waited for HERE: a load whose first use sits in the tile loop would put the compiler's s_waitcnt vmcnt(0) there
+#pragma unroll
+        for (int cc = 0; cc < HC_CPW; ++cc)
+#pragma unroll
+            for (int w = 0; w < HC_NTB; ++w) asm volatile("" : "+v"(tb[cc][w]));
+    }
+
+    // ---- window DMA: piece p covers bytes [1024 p, 1024 p + 1024) of the padded image; lane l carries the 16 bytes at
+    //      1024 p + 16 l = block * 3,088 + within  <-  stream byte  block * 3,072 + within  (pad chunks re-fetch the block's last
+    //      chunk and are never read).  This wave issues pieces wave, wave + HC_NW, ... (past the last piece: the last piece again,
+    //      same bytes to the same place, so that every wave issues HC_PPW pieces and the vmcnt arithmetic is one constant).
+    uint32_t dma_off[HC_PPW];
+#pragma unroll
+    for (int i = 0; i < HC_PPW; ++i) {
+        int p = wave + HC_NW * i;
+        p = p < HC_NPIECE ? p : HC_NPIECE - 1;
+        const int o = 1024 * p + 16 * lane;
+        const int blk = o / HC_BLKB, within = o - HC_BLKB * blk;
+        dma_off[i] = (uint32_t)(32 * HC_ROWB * blk + (within < 32 * HC_ROWB ? within : 32 * HC_ROWB - 16));
+    }
+    auto dma_win = [&](const Cur& c, int buf) {
+        // descriptor of this tile of the (group, batch row) stream: base = first row of the tile, num_records = bytes up to the
+        // end of the row's T tokens (the hardware returns zeros beyond: the ragged last tile needs no clamping)
+        const int64_t row0 = (int64_t)cg * a.z_group_rows + (int64_t)c.b * Ti + (int64_t)c.tile * HC_TT;
+        const uint64_t a64 = (uint64_t)(a.z + row0 * HC_ROWB);
+        const int64_t left = ((int64_t)Ti - (int64_t)c.tile * HC_TT) * HC_ROWB;
+        hc_srd d;
+        d[0] = (int)(uint32_t)a64;
+        d[1] = (int)(uint32_t)(a64 >> 32);
+        d[2] = (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0);
+        d[3] = 0x00020000;
+        const uint32_t base = lds0 + HC_OFF_WIN + buf * HC_WINB;
+#pragma unroll
+        for (int i = 0; i < HC_PPW; ++i) {
+            int p = wave + HC_NW * i;
+            p = p < HC_NPIECE ? p : HC_NPIECE - 1;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         ::"s"(base + 1024 * p), "v"(dma_off[i]), "s"(d) : "memory", "m0");
+        }
+    };
+
+    // ---- per-lane LDS addresses (buffer 0; + HC_WINB / + HC_STGB / + 192 for buffer 1)
+    //   window row of step 8 lq + i of block la: (32 la + 8 lq + i) * 96 + la * 16; the two history rows of the lanes with lq = 0
+    //   lie in the previous block (16 B pad in between) or, for block 0, in the halo slot
+    const uint32_t win_main = HC_OFF_WIN + (32 * la + 8 * lq) * HC_ROWB + la * 16 + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+    const uint32_t win_hist0 = lq > 0 ? win_main - 2 * HC_ROWB : (la > 0 ? win_main - 2 * HC_ROWB - 16 : 0u);   // (la = 0, lq = 0: halo)
+    const uint32_t halo_rd = HC_OFF_HALO + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+    const bool from_halo = lane == 0;
+    const uint32_t stg_wr = HC_OFF_STG + (32 * la + 8 * lq) * 32 + la * 16 + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+    const uint64_t y64 = (uint64_t)a.y;
+    const hc_u32x4 ysrd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.B * Ti * a.y_rowbytes), 0x00020000u};
+    const uint32_t yrb = (uint32_t)a.y_rowbytes;
+
+    float carry[HC_CPW][4];                                  // tile-entering state: components 4 lq .. 4 lq + 3, valid in lanes la = 0
+    const float first_blk = la == 0 ? 1.f : 0.f;
+
+    // ---- store of tile `c` from staging buffer `buf`: the wave's HC_RW rows x 32 B, 16 B per lane
+    auto store_tile = [&](const Cur& c, int buf) {
+        const int t0 = c.tile * HC_TT;
+        const bool full = t0 + HC_TT <= Ti;
+        const uint32_t row0 = (uint32_t)(((int64_t)c.b * Ti + t0) * a.y_rowbytes + d0 * 2);
+#pragma unroll
+        for (int hs = 0; hs < HC_NST; ++hs) {
+            const int row = HC_RW * wave + 32 * hs + (lane >> 1);
+            const hc_u32x4 v = *(const hc_u32x4*)(smem + HC_OFF_STG + buf * HC_STGB + row * 32 + (row >> 5) * 16 + (lane & 1) * 16);
+            // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
+            // counter sees exactly HC_NST stores per interval
+            const uint32_t off = (full || t0 + row < Ti) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(ysrd) : "memory");
+        }
+    };
+
+    // ---- one tile of this wave's channels
+    auto compute = [&](const Cur& c, int buf, bool next_row_start, auto ragged_t) {
+        constexpr bool RAGGED = decltype(ragged_t)::value;
+        const int t0 = c.tile * HC_TT;
+        const bool last_tile = c.tile == a.n_tiles - 1;
+        if (c.tile == 0) {                                   // a new sequence: zero state or the carried one
+#pragma unroll
+            for (int cc = 0; cc < HC_CPW; ++cc) {
+                hc_f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+                if (a.s0) {                                  // (inline asm: a visible load would put s_waitcnt vmcnt(0) into every tile)
+                    const float* sp = a.s0 + ((int64_t)c.b * a.D + d0 + ch0 + cc) * 16 + 4 * lq;
+                    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(c4) : "v"(sp) : "memory");
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) carry[cc][r] = c4[r];
+            }
+        }
+        // the window: ten rows (two of history) x three signals, 8 bytes = 4 channels each -- ALL reads first
+        const uint32_t wm = win_main + buf * HC_WINB;
+        const uint32_t wh = from_halo ? halo_rd + buf * (2 * HC_ROWB) : win_hist0 + buf * HC_WINB;
+        constexpr int NQ = HC_CPW == 4 ? 2 : 1;             // dwords per read
+        uint32_t raw[3][10][NQ];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                if (SO && g == 0) { for (int e = 0; e < NQ; ++e) raw[g][i][e] = 0u; continue; }
+                const unsigned char* p = smem + (i < 2 ? wh + i * HC_ROWB : wm + (i - 2) * HC_ROWB) + 32 * g;
+                if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; raw[g][i][0] = v[0]; raw[g][i][NQ - 1] = v[1]; }
+                else raw[g][i][0] = *(const uint32_t*)p;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // rows 510, 511 of this tile are the history of the next one: lane 63 holds them (its rows 8, 9)
+        if (lane == 63 && !next_row_start) {
+            unsigned char* hp = smem + HC_OFF_HALO + (buf ^ 1) * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (HC_CPW == 4) { hc_u32x2 v = {raw[g][8 + i][0], raw[g][8 + i][NQ - 1]}; *(hc_u32x2*)(hp + i * HC_ROWB + 32 * g) = v; }
+                    else *(uint32_t*)(hp + i * HC_ROWB + 32 * g) = raw[g][8 + i][0];
+                }
+        }
+        const int n_valid = RAGGED ? Ti - (t0 + 32 * la + 8 * lq) : 8;         // steps of this lane inside the sequence
+
+        bf16x8_t xh[HC_CPW];
+#if HC_XLO
+        bf16x8_t xl[HC_CPW];
+#endif
+        f32x2_t x2f[HC_NPAIR][8];
+#pragma unroll
+        for (int pp = 0; pp < HC_NPAIR; ++pp) {
+            // FIR of x1 and v, x = x1 * v; the lane's eight steps of both channels -> the two channels' B operands
+            f32x2_t x[8];
+            {
+                const f32x2_t* fp_ = fwl + pp * 12;
+                const f32x2_t w10 = fp_[4], w11 = fp_[5], w12 = fp_[6], b1 = fp_[7];
+                const f32x2_t w20 = fp_[8], w21 = fp_[9], w22 = fp_[10], b2 = fp_[11];
+                f32x2_t m2a = hc_bf2(raw[1][0][pp]), m1a = hc_bf2(raw[1][1][pp]), m2b = hc_bf2(raw[2][0][pp]), m1b = hc_bf2(raw[2][1][pp]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2_t ca = hc_bf2(raw[1][i + 2][pp]), cb = hc_bf2(raw[2][i + 2][pp]);
+                    const f32x2_t x1c = hc_fma(w12, ca, hc_fma(w11, m1a, hc_fma(w10, m2a, b1)));
+                    const f32x2_t vc = hc_fma(w22, cb, hc_fma(w21, m1b, hc_fma(w20, m2b, b2)));
+                    x[i] = x1c * vc;
+                    if (RAGGED && i >= n_valid) { x[i][0] = 0.f; x[i][1] = 0.f; }      // past the end: nothing enters the modes
+                    m2a = m1a; m1a = ca; m2b = m1b; m1b = cb;
+                }
+            }
+            if (!SO) {
+                const f32x2_t* fp_ = fwl + pp * 12;
+                const f32x2_t w00 = fp_[0], w01 = fp_[1], w02 = fp_[2], b0f = fp_[3];
+                f32x2_t m2 = hc_bf2(raw[0][0][pp]), m1 = hc_bf2(raw[0][1][pp]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2_t cx = hc_bf2(raw[0][i + 2][pp]);
+                    x2f[pp][i] = hc_fma(w02, cx, hc_fma(w01, m1, hc_fma(w00, m2, b0f)));
+                    m2 = m1; m1 = cx;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                uint32_t hw[4];
+#if HC_XLO
+                uint32_t lw[4];
+#endif
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hw[j] = pack_bf2(x[2 * j][e], x[2 * j + 1][e]);
+#if HC_XLO
+                    lw[j] = pack_bf2(x[2 * j][e] - bf_lo(hw[j]), x[2 * j + 1][e] - bf_hi(hw[j]));
+#endif
+                }
+                xh[2 * pp + e] = __builtin_bit_cast(bf16x8_t, hc_u4(hw[0], hw[1], hw[2], hw[3]));
+#if HC_XLO
+                xl[2 * pp + e] = __builtin_bit_cast(bf16x8_t, hc_u4(lw[0], lw[1], lw[2], lw[3]));
+#endif
+            }
+        }
+
+        // ---- per channel: E = W . X and y0 = T0 . X on the matrix cores, the block scan, y += G . S
+        hc_f32x4 yv[HC_CPW][2];
+#pragma unroll
+        for (int cc = 0; cc < HC_CPW; ++cc) {
+            const uint32_t* t_ = tb[cc];
+#define HC_FRAG(BASE) __builtin_bit_cast(bf16x8_t, hc_u4(t_[(BASE)], t_[(BASE) + 1], t_[(BASE) + 2], t_[(BASE) + 3]))
+            const hc_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            hc_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(20), xh[cc], zero4, 0, 0, 0);       // W_mid . X_hi
+#if HC_XLO
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(16), xl[cc], e, 0, 0, 0);                    // W_hi . X_lo
+#endif
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(16), xh[cc], e, 0, 0, 0);                    // W_hi . X_hi
+            if (!SO)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    hc_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(8 * mt + 4), xh[cc], zero4, 0, 0, 0);
+#if HC_XLO
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(8 * mt), xl[cc], acc, 0, 0, 0);
+#endif
+                    yv[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(8 * mt), xh[cc], acc, 0, 0, 0);
+                }
+            HC_FENCE_NOP();
+            // Kogge-Stone scan of the 16 block aggregates -> state entering every block; the tile's end state
+            float sv[4] = {e[0], e[1], e[2], e[3]};
+            const hc_f32x4* pwc = (const hc_f32x4*)(pwl + (ch0 + cc) * 64) + lq;
+            {
+                const hc_f32x4 P = pwc[0];
+                const float c0 = first_blk * carry[cc][0], c1 = first_blk * carry[cc][1], c2 = first_blk * carry[cc][2], c3 = first_blk * carry[cc][3];
+                sv[0] = fmaf(-P[1], c1, fmaf(P[0], c0, sv[0]));
+                sv[1] = fmaf(P[1], c0, fmaf(P[0], c1, sv[1]));
+                sv[2] = fmaf(-P[3], c3, fmaf(P[2], c2, sv[2]));
+                sv[3] = fmaf(P[3], c2, fmaf(P[2], c3, sv[3]));
+            }
+#define HC_LEVEL(KK, SH)                                                                              \
+            {                                                                                         \
+                const hc_f32x4 P = pwc[4 * (KK)];                                                     \
+                const float u0 = hc_shr<SH>(sv[0]), u1 = hc_shr<SH>(sv[1]);                           \
+                const float u2 = hc_shr<SH>(sv[2]), u3 = hc_shr<SH>(sv[3]);                           \
+                sv[0] = fmaf(-P[1], u1, fmaf(P[0], u0, sv[0]));                                        \
+                sv[1] = fmaf(P[1], u0, fmaf(P[0], u1, sv[1]));                                         \
+                sv[2] = fmaf(-P[3], u3, fmaf(P[2], u2, sv[2]));                                        \
+                sv[3] = fmaf(P[3], u2, fmaf(P[2], u3, sv[3]));                                         \
+            }
+            HC_LEVEL(0, 1) HC_LEVEL(1, 2) HC_LEVEL(2, 4) HC_LEVEL(3, 8)
+#undef HC_LEVEL
+            float st[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[r] = hc_shr<1>(sv[r]) + first_blk * carry[cc][r];                 // state ENTERING block la
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[r]), 0x121, 0xf, 0xf, false));
+            if (WS && last_tile) {
+                // state after the last token T - 1, which sits in block a_ at local step r_ - 1: the recurrence over the block's first
+                // r_ steps from the state entering it.  Lane s (< 8) takes mode s.  The x values are the very bf16 terms the matrix
+                // cores consumed: the channel's fragments go through the wave's scratch planes (hi | lo, time-contiguous).
+                unsigned char* xs = smem + HC_OFF_XS + wave * 2048;
+                *(bf16x8_t*)(xs + (4 * la + lq) * 16) = xh[cc];
+#if HC_XLO
+                *(bf16x8_t*)(xs + 1024 + (4 * la + lq) * 16) = xl[cc];
+#endif
+                const int tin = Ti - t0;                     // 1..512 valid steps of this tile
+                const int a_ = (tin - 1) >> 5, r_ = tin - 32 * a_;
+                const int src = (16 * ((lane & 7) >> 1) + a_) * 4;
+                float g4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g4[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, st[r])));
+                float sre = (lane & 1) ? g4[2] : g4[0], sim = (lane & 1) ? g4[3] : g4[1];
+                const int dch = d0 + ch0 + cc;
+                f32x2_t pp2;
+                {
+                    const float* qp = a.poles + ((int64_t)dch * 8 + (lane & 7)) * 2;
+                    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(pp2) : "v"(qp) : "memory");
+                }
+                const float pre = pp2[0], pim = pp2[1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int j = 0; j < r_; ++j) {
+                    const unsigned char* up = xs + (4 * a_ + (j >> 3)) * 16 + (j & 7) * 2;
+                    float xv = bf_to_f(*(const uint16_t*)up);
+#if HC_XLO
+                    xv += bf_to_f(*(const uint16_t*)(up + 1024));
+#endif
+                    const float nre = fmaf(pre, sre, fmaf(-pim, sim, xv));
+                    sim = fmaf(pre, sim, pim * sre);
+                    sre = nre;
+                }
+                if (lane < 8) {
+                    float* so = a.s_out + ((int64_t)c.b * a.D + dch) * 16 + 2 * lane;
+                    const f32x2_t sv2 = {sre, sim};
+                    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" :: "v"(so), "v"(sv2) : "memory");
+                }
+            }
+            if (!SO) {
+                // y += G . S_start with the block states split hi + lo on the fly
+                const uint32_t h01 = pack_bf2(st[0], st[1]), h23 = pack_bf2(st[2], st[3]);
+                const uint32_t l01 = pack_bf2(st[0] - bf_lo(h01), st[1] - bf_hi(h01));
+                const uint32_t l23 = pack_bf2(st[2] - bf_lo(h23), st[3] - bf_hi(h23));
+                const bf16x8_t sb = __builtin_bit_cast(bf16x8_t, hc_u4(h01, h23, l01, l23));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const uint32_t* g_ = t_ + 24 + 4 * mt;
+                    yv[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hc_u4(g_[0], g_[1], g_[0], g_[1])),
+                                                                       sb, yv[cc][mt], 0, 0, 0);
+                    yv[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hc_u4(g_[2], g_[3], 0u, 0u)),
+                                                                       sb, yv[cc][mt], 0, 0, 0);
+                }
+                HC_FENCE_NOP();
+            }
+#undef HC_FRAG
+        }
+        // ---- gate and stage: accumulator (mt, r) of a lane is its step 4 mt + r; one dword (two channels) per step and pair
+        if (!SO) {
+            unsigned char* sp = smem + stg_wr + buf * HC_STGB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t o[HC_NPAIR];
+#pragma unroll
+                for (int pp = 0; pp < HC_NPAIR; ++pp)
+                    o[pp] = pack_bf2(yv[2 * pp][i >> 2][i & 3] * x2f[pp][i][0], yv[2 * pp + 1][i >> 2][i & 3] * x2f[pp][i][1]);
+                if (HC_CPW == 4) { hc_u32x2 v = {o[0], o[HC_NPAIR - 1]}; *(hc_u32x2*)(sp + i * 32) = v; }
+                else *(uint32_t*)(sp + i * 32) = o[0];
+            }
+        }
+    };
+
+    // ---- the pipeline: one barrier per tile.  VM queue of a wave per interval, in issue order: HC_PPW DMA pieces of window(k + 1),
+    //      HC_NST stores of tile k - 1; it retires in order, so before the barrier of interval k + 1 "window(k + 1) landed" is
+    //      vmcnt(HC_NST) -- the stores may stay in flight.
+    Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
+    if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
+    for (int k = 0; k <= n_steps; ++k) {
+        const int buf = k & 1;
+        if (k < n_steps) {
+            if (c_cmp.tile == 0 && wave == 0 && lane < 48) {  // a new row: its FIR history (or zeros) into this tile's halo slot
+                const int r = lane / 24, wq = lane - 24 * r; // 24 dwords per row: x2 | x1 | v
+                uint32_t v = 0u;
+                if (a.z_halo) {
+                    const uint32_t* hp = a.z_halo + ((int64_t)c_cmp.b * 2 + r) * (a.D * 6 / 4) + cg * (HC_ROWB / 4) + wq;
+                    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(hp) : "memory");
+                }
+                *(uint32_t*)(smem + HC_OFF_HALO + buf * (2 * HC_ROWB) + r * HC_ROWB + wq * 4) = v;
+            }
+            if (!SO && k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                     // window(k) and the halo slot -> everybody; staging(k - 1) complete
+        if (k + 1 < n_steps) { dma_win(c_dma, buf ^ 1); advance(c_dma); }
+        if (!SO && k >= 1) { store_tile(c_st, buf ^ 1); advance(c_st); }
+        if (k < n_steps) {
+            Cur nx = c_cmp;
+            advance(nx);
+            const bool next_row_start = nx.tile == 0;
+            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, next_row_start, hc_false{});
+            else compute(c_cmp, buf, next_row_start, hc_true{});
+            c_cmp = nx;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool SO, bool WS>
+__global__ __launch_bounds__(HC_THREADS, 1) void hyena_cs_kernel(HcArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HC_LDS];      // the only LDS object
+#if HC_CPW == 4
+    hc_run<SO, WS, 0>(a, smem);
+#else
+    if (threadIdx.x & 64) hc_run<SO, WS, 1>(a, smem);            // (wave-uniform: the two waves of a quad take its two channel pairs)
+    else hc_run<SO, WS, 0>(a, smem);
+#endif
+}
+
+extern "C" int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
+                               const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
+                               int64_t z_group_rows, int64_t state_only, void* stream) {
+    if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0 || D != n_heads * 128) return -1;
+    const int64_t yrb = D * 2;
+    if (B * T * yrb >= 0xfffffff0ll || T * HC_ROWB >= 0x7fffffffll) return -1;     // 32-bit offsets inside y / one stream of z
+    if (z_group_rows < B * T) return -1;
+    if (s_out && !poles) return -1;
+    if (state_only ? !s_out : !y) return -1;
+    const int64_t groups = D / HC_CH;
+    // workgroups = groups x nb_split, ~one per CU: a workgroup walks batch rows b0, b0 + nb_split, ... of its group
+    int64_t nb_split = (256 + groups - 1) / groups;
+    if (nb_split > B) nb_split = B;
+    const int64_t streams = groups * nb_split;
+    if (streams % 8 != 0 || B * groups > 0x7fffffff) return -1;                      // equal runs of streams per XCD
+    HcArgs a;
+    a.z = (const unsigned char*)z; a.z_halo = (const uint32_t*)z_halo; a.fir_w = (const uint16_t*)fir_w; a.fir_b = (const uint16_t*)fir_b;
+    a.tab = (const uint32_t*)table; a.y = (unsigned char*)y; a.s0 = s0; a.s_out = s_out; a.poles = poles;
+    a.B = (int)B; a.T = (int)T; a.D = (int)D; a.n_tiles = (int)((T + HC_TT - 1) / HC_TT); a.n_groups = (int)groups;
+    a.nb_split = (int)nb_split; a.z_group_rows = z_group_rows; a.y_rowbytes = yrb;
+    if (state_only) hipLaunchKernelGGL((hyena_cs_kernel<true, true>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);
+    else if (s_out) hipLaunchKernelGGL((hyena_cs_kernel<false, true>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((hyena_cs_kernel<false, false>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);
+    return evo_launch_status();
+}

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "evo_mlp_gate_mfma_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
+    "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 6 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -51,7 +52,7 @@ _SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 5          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 6          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -176,6 +177,8 @@ class HipOps:
         self.timer: Optional[KernelTimer] = None
         self.validate_ids = os.environ.get("EVO_AMD_VALIDATE_IDS", "1") != "0"   # one 4-byte D2H read per forward
         self.hyena_mfma = os.environ.get("EVO_AMD_HYENA", "mfma").lower() != "modal"   # single-pass matrix-core operator
+        # ... on group-major z by the channel-stationary kernel (csrc/hyena_cs.hip, round 4); EVO_AMD_HYENA_CS=0: the round-3 kernel
+        self.hyena_cs_flag = os.environ.get("EVO_AMD_HYENA_CS", "1") != "0"
         self.last_hyena_io = {}
 
     def _t(self, name):
@@ -452,15 +455,61 @@ class HipOps:
             assert tuple(poles.shape) == (D, 8, 2)
             s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
         y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
-        fn = self.lib.evo_hyena_mfma if zg_shape is None else self.lib.evo_hyena_mfma_zg
-        with self._t("hyena_mfma"):
-            _check(fn(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(),
-                      table.data_ptr(), y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles),
-                      B, T, D, n_heads, _stream()), "evo_hyena_mfma" if zg_shape is None else "evo_hyena_mfma_zg")
+        if zg_shape is not None and self.hyena_cs_flag:
+            with self._t("hyena_mfma"):
+                _check(self.lib.evo_hyena_cs_zg(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(),
+                                                y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, B * T, 0,
+                                                _stream()), "evo_hyena_cs_zg")
+        else:
+            fn = self.lib.evo_hyena_mfma if zg_shape is None else self.lib.evo_hyena_mfma_zg
+            with self._t("hyena_mfma"):
+                _check(fn(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(),
+                          table.data_ptr(), y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles),
+                          B, T, D, n_heads, _stream()), "evo_hyena_mfma" if zg_shape is None else "evo_hyena_mfma_zg")
         self.last_hyena_io = {"mfma": z.numel() * 2 + y.numel() * 2}
         if want_state:
             return y, torch.view_as_complex(s_fin)
         return y
+
+    def hyena_cs(self, zg, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
+                 state_only=False, row0=0):
+        """The channel-stationary single-pass operator (csrc/hyena_cs.hip: evo_hyena_cs_zg) on B batch rows of T tokens of a
+        GROUP-MAJOR z [D / 16, rows_total, 48] bf16 (linear_zg's result), the first at row `row0` of every group's plane
+        (`row0` = b0 * T selects a sub-range of batch rows of a larger tensor: the row groups of a sequence-parallel shard).
+        -> y [B,T,D] bf16 | (y, end state [B,D,8] complex64) with `want_state` | the end state alone with `state_only`
+        (stage 1 of a sequence-parallel shard: nothing else is written).  `z_halo` [B,2,3D] (grouped column order), `s0`
+        [B,D,8] complex: FIR history / modal state before the first token."""
+        self._need(zg, torch.bfloat16, "hyena z (group-major)")
+        G, rows_total, w48 = zg.shape
+        D = G * 16
+        assert w48 == 48 and 0 <= row0 and row0 + B * T <= rows_total
+        if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
+            raise RuntimeError("hyena_cs: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
+        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b")):
+            self._need(t, torch.bfloat16, "hyena " + nm)
+        if z_halo is not None:
+            self._need(z_halo, torch.bfloat16, "hyena z_halo")
+            assert z_halo.shape == (B, 2, 3 * D)
+        s0r = None
+        if s0 is not None:
+            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
+            assert s0r.shape == (B, D, 8, 2) and s0r.is_cuda
+        s_fin = None
+        if want_state or state_only:
+            if poles is None:
+                raise RuntimeError("hyena_cs: the end state needs the poles")
+            self._need(poles, torch.float32, "hyena poles")
+            assert tuple(poles.shape) == (D, 8, 2)
+            s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=zg.device)
+        y = None if state_only else torch.empty(B, T, D, dtype=torch.bfloat16, device=zg.device)
+        with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
+            _check(self.lib.evo_hyena_cs_zg(zg.data_ptr() + row0 * 96, _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
+                                            table.data_ptr(), _ptr(y), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads,
+                                            rows_total, 1 if state_only else 0, _stream()), "evo_hyena_cs_zg")
+        if state_only:
+            return torch.view_as_complex(s_fin)
+        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + y.numel() * 2}
+        return (y, torch.view_as_complex(s_fin)) if want_state else y
 
     def hyena_mfma_state(self, z, fir_w, fir_b, table, n_heads, poles, z_halo=None, s0=None) -> torch.Tensor:
         """End state [B,D,8] complex64 of the modal recurrence over z [B,T,3D] (GROUPED layout) -- the walk of

@@ -30,8 +30,9 @@ extern "C" {
  *   3: evo_rope_append_decode_bf16 added; the fused decode launches take up to 8 rows at K = 4096.
  *   4: evo_hyena_mfma gained the carry-in state `s0`, the end state `s_out` and `poles`; evo_hyena_mfma_state added.
  *   5: evo_mlp_gate_mfma_bf16 (GELU * gate in the dense layer's epilogue), evo_linear_zg_mfma_bf16 (group-major result) and
- *      evo_hyena_mfma_zg (the single-pass operator on group-major z) added. */
-#define EVO_ABI_VERSION 5
+ *      evo_hyena_mfma_zg (the single-pass operator on group-major z) added.
+ *   6: evo_hyena_cs_zg (the single-pass operator with channel-stationary waves: outputs, end state or state-only walk) added. */
+#define EVO_ABI_VERSION 6
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -124,6 +125,21 @@ int evo_hyena_mfma_state(const void* z, const void* z_halo, const void* fir_w, c
 int evo_hyena_mfma_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* dskip,
                       const void* table, void* y, const float* s0, float* s_out, const float* poles,
                       int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream);
+
+/* The same operator -- HyenaInferenceEngine.parallel_fir + compute_filter + parallel_iir (+ prefill_via_modal_fft with `s_out`)
+ *                                                      [REF evo/configs/evo-1-8k-base_inference.yml:8,10,14,33,37; evo/generation.py:111-114]
+ * -- on group-major z with CHANNEL-STATIONARY waves (csrc/hyena_cs.hip, round 4): a wave owns 2 (or 4) channels of the group for the
+ * whole 512-step tile, its lanes' FIR outputs ARE the B operands of the block MFMAs and its accumulators meet the FIR'd x2 of the same
+ * lane, so no bf16 planes, no parked x2 and no fp32 y^T travel through LDS (hyena_mfma.hip: three LDS round trips per value).
+ * z [D / 16][z_group_rows >= B T][48] bf16: batch row b of group g starts at row g * z_group_rows + b * T (so a caller can hand a
+ * sub-range of batch rows of a larger tensor: z pointer advanced by b0 * T * 96 bytes, z_group_rows = the tensor's B_total * T).
+ * z_halo [B, 2, 3 D] bf16 (grouped column order) or NULL; table = the int32 [D, 52, 64] operand table of evo_amd/hyena_tables.py
+ * (filter.D folded into the block-Toeplitz diagonal); y [B, T, D] bf16; s0 / s_out [B, D, 8, 2] f32 or NULL; poles [D, 8, 2] f32
+ * (needed with s_out).  state_only != 0: no y (may be NULL), only s_out -- stage 1 of a sequence-parallel shard.
+ * Same arithmetic as evo_hyena_mfma_zg (results agree to fp32 rounding of the block scan).  D == n_heads * 128. */
+int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
+                    const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
+                    int64_t z_group_rows, int64_t state_only, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
  * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]

@@ -495,3 +495,91 @@ def test_hyena_mfma_group_major_z_is_bitwise_the_token_major_launch(ops, B, T, D
     ry, _ = R.op_hyena(z.cpu(), *prm, H)
     y_g = ops.hyena_mfma_prefill(zg, fir_w, fir_b, dskip, tab, H, zg_shape=(B, T))
     assert_close_bf16(y_g, ry)
+
+
+# ---- round 4: the channel-stationary single-pass operator (csrc/hyena_cs.hip) ---------------------------------------------------
+@pytest.mark.parametrize("B,T,D,H", [
+    (2, 37, 128, 1),             # one ragged tile
+    (1, 1, 128, 1),              # single token
+    (2, 513, 256, 2),            # a full tile + 1 row: the tile-to-tile carry and the FIR history slot
+    (1, 513, 4096, 32),          # BASELINE configs[0] length at the real width
+    (2, 8193, 256, 2),           # BASELINE configs[1] length: 17 tiles
+    (1, 3000, 128, 1),
+    (40, 300, 128, 1),           # more batch rows than row streams: workgroups walk several rows (history slot re-seeded per row)
+    (3, 1100, 256, 2),           # the pipeline crosses a row boundary mid-stream
+    (8, 2049, 1024, 8),
+    (9, 1024, 256, 2),           # T a multiple of the tile: no ragged tile at all
+])
+def test_hyena_cs_matches_oracle_and_the_round3_kernel(ops, B, T, D, H):
+    """evo_hyena_cs_zg (round 4: channel-stationary waves, no planes / parked x2 / fp32 y^T in LDS) vs the fp64 oracle -- outputs and
+    end state, with and without FIR history and a carry-in state, and the state-only walk -- and vs evo_hyena_mfma_zg, whose
+    arithmetic it repeats term for term (only the block scan's FMA contraction may differ: fp32 rounding, i.e. at most a bf16
+    rounding boundary crossed on a small fraction of the outputs)."""
+    from evo_amd.hyena_tables import mfma_operand_table, group_permutation
+    prm = hyena_params(D, 100)
+    fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(101))).to(DEV)
+    halo = bf(torch.randn(B, 2, 3 * D, generator=gen(102))).to(DEV)
+    s0 = torch.view_as_complex(torch.randn(B, D, 8, 2, generator=gen(103)).contiguous()).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    perm = group_permutation(D, H, DEV)
+    zt, hg = z[..., perm].contiguous(), halo[..., perm].contiguous()
+    zg = zt.view(B * T, D // 16, 48).transpose(0, 1).contiguous()                     # [groups, B T, 48]
+    for kw in (dict(), dict(z_halo=hg), dict(z_halo=hg, s0=s0)):
+        y_new, s_new = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles, **kw)
+        y_pln = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, **kw)                     # the scoring instantiation (no end state)
+        assert torch.equal(y_pln, y_new), list(kw)
+        s_only = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, poles=poles, state_only=True, **kw)
+        assert torch.equal(torch.view_as_real(s_only), torch.view_as_real(s_new)), list(kw)
+        ry, rst = R.op_hyena(z.cpu(), *prm, H, **{k: (halo if k == "z_halo" else s0).cpu() for k in kw})
+        assert_close_bf16(y_new, ry, rl2=2e-3 if y_new.numel() > 4096 else 3.5e-3)
+        assert (s_new.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max(), list(kw)
+        keep = ops.hyena_cs_flag
+        ops.hyena_cs_flag = False
+        try:
+            y_old, s_old = ops.hyena_mfma_prefill(zg, fir_w, fir_b, dskip, tab, H, kw.get("z_halo"), s0=kw.get("s0"), want_state=True,
+                                                  poles=poles, zg_shape=(B, T))
+        finally:
+            ops.hyena_cs_flag = keep
+        d = (y_new.double() - y_old.double()).abs()
+        assert (d <= y_old.double().abs() * 2.0 ** -7 + 1e-4 * float(y_old.abs().max())).all(), list(kw)
+        assert float((d > 0).double().mean()) < 0.02, (list(kw), float((d > 0).double().mean()))
+        assert (s_new - s_old).abs().max().item() <= 2e-6 * s_old.abs().max().item()
+
+
+def test_hyena_cs_row_subrange_of_a_larger_group_major_tensor(ops):
+    """`row0` / z_group_rows: the row groups of a sequence-parallel shard are launched on sub-ranges of the batch rows of ONE
+    group-major tensor -- same results as a launch on a copy of just those rows."""
+    from evo_amd.hyena_tables import mfma_operand_table, group_permutation
+    B, T, D, H = 5, 700, 256, 2
+    prm = hyena_params(D, 110)
+    fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(111))).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    zt = z[..., group_permutation(D, H, DEV)].contiguous()
+    zg = zt.view(B * T, D // 16, 48).transpose(0, 1).contiguous()
+    y_all = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H)
+    y_sub = ops.hyena_cs(zg, 2, T, fir_w, fir_b, tab, H, row0=3 * T)
+    assert torch.equal(y_sub, y_all[3:5])
+    zs = zt[1:4].reshape(3 * T, D // 16, 48).transpose(0, 1).contiguous()
+    assert torch.equal(ops.hyena_cs(zs, 3, T, fir_w, fir_b, tab, H), ops.hyena_cs(zg, 3, T, fir_w, fir_b, tab, H, row0=T))
+
+
+def test_hyena_cs_is_bit_reproducible_at_bench_size(ops):
+    """8 x 8,193 x 4096 (BASELINE configs[1]): eight launches on the same data are bit-identical (the hazard stress: two waves
+    of a SIMD share the matrix pipe) and agree with the three-launch modal path to one bf16 rounding."""
+    from evo_amd.hyena_tables import mfma_operand_table, group_permutation
+    B, T, D, H = 8, 8193, 4096, 32
+    prm = [t.to(DEV) for t in hyena_params(D, 64)]
+    fir_w, fir_b, poles, res, dskip = prm
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(65))).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    zg = z[..., group_permutation(D, H, DEV)].view(B * T, D // 16, 48).transpose(0, 1).contiguous()
+    ys = [ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H).clone() for _ in range(8)]
+    for k in range(1, 8):
+        assert torch.equal(ys[k], ys[0]), k
+    ref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    e = (ys[0].double() - ref.double()).abs()
+    assert float(e.norm() / ref.double().norm()) < 3e-4
+    assert (e <= ref.double().abs() * 2.0 ** -7 + float(ref.abs().max()) * 1e-3).all()

@@ -65,7 +65,8 @@ def test_oracle_on_the_gpu_is_the_cpu_oracle(full):
 
 def _engine_generate(m, prompt, n_new, graph, forced=None, taps=False):
     """The token loop of evo_amd.generation.Generator.generate (greedy) written out, so that the residual stream can be
-    tapped: returns (tokens [n_new], logits of the prompt pass [P,V], step logits [n_new,V], cache, taps per forward)."""
+    tapped: returns (tokens [n_new], logits of the prompt pass [P,V], step logits [n_new,V], a snapshot of the Hyena caches
+    right after the prompt pass + the live cache, taps per forward)."""
     m.decode_graph = graph
     m._dgraph = None
     m._dgraph_warm = None
@@ -89,12 +90,14 @@ def _engine_generate(m, prompt, n_new, graph, forced=None, taps=False):
                 m.block_taps = None
         if i == 0:
             prompt_logits = logits[0].float()
+            snap = {"state": {k: v.clone() for k, v in c["hyena"].state_dict.items()},
+                    "fir": {k: v.clone() for k, v in c["hyena"].fir_state_dict.items()}, "cache": c}
         last = logits[:, -1].float()
         step_logits.append(last[0])
         tok = last.argmax(-1) if forced is None else forced[i:i + 1]
         toks.append(tok)
         x = tok[:, None]
-    return torch.cat(toks), prompt_logits, torch.stack(step_logits), c, all_taps
+    return torch.cat(toks), prompt_logits, torch.stack(step_logits), snap, all_taps
 
 
 def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
@@ -137,12 +140,12 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
         if not (err <= PIN_BLOCK[kind] and hu <= PIN_BLOCK["hulp"] and upd <= PIN_BLOCK["upd"]):
             bad.append(("prompt", i, kind, err, hu, upd))
         if kind == "hyena":                                    # what the prompt pass leaves in the caches (same block input)
-            se, sr = cache["hyena"].state_dict[i].to(torch.complex128), oc["hyena"].state_dict[i].to(torch.complex128)
+            se, sr = cache["state"][i].to(torch.complex128), oc["hyena"].state_dict[i].to(torch.complex128)
             state_rel = max(state_rel, ((se - sr).abs().max() / sr.abs().max()).item())
-            fe, fr = cache["hyena"].fir_state_dict[i].double(), oc["hyena"].fir_state_dict[i].double()
+            fe, fr = cache["fir"][i].double(), oc["hyena"].fir_state_dict[i].double()
             fir_max = max(fir_max, ((fe - fr).abs() / (fr.abs() * 2.0 ** -8 + fr.abs().max() * 2e-3)).max().item())
         else:
-            ke = cache["mha"].key_value_memory_dict[i][:1, :P].double()
+            ke = cache["cache"]["mha"].key_value_memory_dict[i][:1, :P].double()     # (rows 0..P-1: untouched by the decode steps)
             kr = oc["mha"].key_value_memory_dict[i][:1, :P].double()
             kv_rel = max(kv_rel, ((ke - kr).norm() / kr.norm()).item())
         del ref, got, u
@@ -262,14 +265,30 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     sharded = torch.cat([o[1] for o in outs], 1)
     assert sharded.shape == full_logits.shape
     err = rel_l2(sharded, full_logits)
-    worst_shard = max(rel_l2(o[1], full_logits[:, o[0][1]:o[0][2]]) for o in outs)
+    per_shard = [rel_l2(o[1], full_logits[:, o[0][1]:o[0][2]]) for o in outs]
     lp = torch.cat([o[2] for o in outs], 1).double().cpu()
     want = logits_to_logprobs(full_logits.float().cpu(), ids.cpu(), trim_bos=True).double()
     assert lp.shape == want.shape
     dlp, dscore = (lp - want).abs().mean().item(), (abs(lp.mean() - want.mean()) / abs(want.mean())).item()
+    # the yardstick at THESE dimensions: the unsharded forward once more with every dense layer on the other kernel routing
+    # (all hand-written): the same arithmetic in another tiling / summation order -- what "bf16 noise of another tiling
+    # through 4 blocks" amounts to at D = 4096 (the toy models of the two-process test measure 4.5e-3)
+    was = ops.all_gemm_mfma
+    ops.all_gemm_mfma = not was
+    try:
+        with torch.inference_mode():
+            other = m(ids)[0]
+    finally:
+        ops.all_gemm_mfma = was
+    noise = rel_l2(other, full_logits)
+    noise_shards = [rel_l2(other[:, o[0][1]:o[0][2]], full_logits[:, o[0][1]:o[0][2]]) for o in outs]
+    del other
     print(f"[configs3, 8 virtual ranks x 16,385 tokens, D = 4096, 4 layers] sharded vs unsharded HIP forward: logits rel-L2 {err:.3e} "
-          f"(worst shard {worst_shard:.3e}), mean |d logprob| {dlp:.2e}, score rel {dscore:.2e}")
-    assert err < 8e-3 and worst_shard < 1.2e-2                 # bf16 noise of another tiling through 4 blocks (two-process test: 8e-3)
+          f"(per shard {' '.join(f'{x:.2e}' for x in per_shard)}), mean |d logprob| {dlp:.2e}, score rel {dscore:.2e}; "
+          f"tiling-noise yardstick (unsharded, other dense-layer routing): {noise:.3e} (per shard {' '.join(f'{x:.2e}' for x in noise_shards)})")
+    # shard 0 has no carry-in, no halo and sees only its own keys: its distance is tiling noise alone; the other shards add
+    # the fp32 carry / pole-power arithmetic, which must not show at this scale
+    sharded_ok = err <= max(1.5 * noise, 8e-3) and max(per_shard) <= max(1.5 * max(noise_shards), 1.5 * per_shard[0], 1.2e-2)
     assert dlp < 5e-2 and dscore < 3e-3
 
     # ---- shard 7's Hyena output of layer 0 (carry from 7 predecessors) vs the fp64 FFT long convolution over the WHOLE sequence
@@ -307,3 +326,4 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
           f"over all 131,073 tokens, heads {heads}: rel-L2 {worst_rl2:.3e}, worst excess over the bf16 bound {worst_ex:.3e} "
           f"({time.time() - t0:.1f} s)")
     assert worst_ex <= 0.0 and worst_rl2 < 2e-3
+    assert sharded_ok, (err, noise, per_shard)
