@@ -58,6 +58,12 @@
 #define HC_OFF_XS (HC_OFF_FW + 768)                     // end-state scratch: per wave the hi | lo planes of one channel (2 KiB)
 #define HC_LDS (HC_OFF_XS + HC_NW * 2048)
 static_assert(HC_LDS <= 160 * 1024, "LDS");
+#ifndef HC_PROFILE
+#define HC_PROFILE 0
+#endif
+#ifndef HC_AHEAD
+#define HC_AHEAD 2                          // window tiles in flight: 2 (two barriers per tile, the buffer refilled as soon as it is in registers) | 1
+#endif
 #define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
 
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
@@ -237,8 +243,44 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         }
     };
 
-    // ---- one tile of this wave's channels
-    auto compute = [&](const Cur& c, int buf, bool next_row_start, auto ragged_t) {
+    // ---- the window of a tile into registers: ten rows (two of history) x three signals, 8 bytes = 4 channels each -- ALL reads
+    //      first, one LDS round trip; then the window buffer is free again (HC_AHEAD = 2: it is refilled right away)
+    constexpr int NQ = HC_CPW == 4 ? 2 : 1;                  // dwords per read
+    uint32_t raw[3][10][NQ];
+    auto read_win = [&](int buf, bool next_row_start) {
+        const uint32_t wm = win_main + buf * HC_WINB;
+        const uint32_t wh = from_halo ? halo_rd + buf * (2 * HC_ROWB) : win_hist0 + buf * HC_WINB;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                if (SO && g == 0) { for (int e = 0; e < NQ; ++e) raw[g][i][e] = 0u; continue; }
+                const unsigned char* p = smem + (i < 2 ? wh + i * HC_ROWB : wm + (i - 2) * HC_ROWB) + 32 * g;
+                if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; raw[g][i][0] = v[0]; raw[g][i][NQ - 1] = v[1]; }
+                else raw[g][i][0] = *(const uint32_t*)p;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) asm volatile("" : "+v"(raw[g][i][e]));            // (kept as loaded: no re-read behind the barrier)
+        // rows 510, 511 of this tile are the history of the next one: lane 63 holds them (its rows 8, 9)
+        if (lane == 63 && !next_row_start) {
+            unsigned char* hp = smem + HC_OFF_HALO + (buf ^ 1) * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (HC_CPW == 4) { hc_u32x2 v = {raw[g][8 + i][0], raw[g][8 + i][NQ - 1]}; *(hc_u32x2*)(hp + i * HC_ROWB + 32 * g) = v; }
+                    else *(uint32_t*)(hp + i * HC_ROWB + 32 * g) = raw[g][8 + i][0];
+                }
+        }
+    };
+
+    // ---- one tile of this wave's channels, from the registers read_win filled
+    auto compute = [&](const Cur& c, int buf, auto ragged_t) {
         constexpr bool RAGGED = decltype(ragged_t)::value;
         const int t0 = c.tile * HC_TT;
         const bool last_tile = c.tile == a.n_tiles - 1;
@@ -253,32 +295,6 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) carry[cc][r] = c4[r];
             }
-        }
-        // the window: ten rows (two of history) x three signals, 8 bytes = 4 channels each -- ALL reads first
-        const uint32_t wm = win_main + buf * HC_WINB;
-        const uint32_t wh = from_halo ? halo_rd + buf * (2 * HC_ROWB) : win_hist0 + buf * HC_WINB;
-        constexpr int NQ = HC_CPW == 4 ? 2 : 1;             // dwords per read
-        uint32_t raw[3][10][NQ];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                if (SO && g == 0) { for (int e = 0; e < NQ; ++e) raw[g][i][e] = 0u; continue; }
-                const unsigned char* p = smem + (i < 2 ? wh + i * HC_ROWB : wm + (i - 2) * HC_ROWB) + 32 * g;
-                if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; raw[g][i][0] = v[0]; raw[g][i][NQ - 1] = v[1]; }
-                else raw[g][i][0] = *(const uint32_t*)p;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // rows 510, 511 of this tile are the history of the next one: lane 63 holds them (its rows 8, 9)
-        if (lane == 63 && !next_row_start) {
-            unsigned char* hp = smem + HC_OFF_HALO + (buf ^ 1) * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (HC_CPW == 4) { hc_u32x2 v = {raw[g][8 + i][0], raw[g][8 + i][NQ - 1]}; *(hc_u32x2*)(hp + i * HC_ROWB + 32 * g) = v; }
-                    else *(uint32_t*)(hp + i * HC_ROWB + 32 * g) = raw[g][8 + i][0];
-                }
         }
         const int n_valid = RAGGED ? Ti - (t0 + 32 * la + 8 * lq) : 8;         // steps of this lane inside the sequence
 
@@ -370,17 +386,34 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 sv[2] = fmaf(-P[3], c3, fmaf(P[2], c2, sv[2]));
                 sv[3] = fmaf(P[3], c2, fmaf(P[2], c3, sv[3]));
             }
-#define HC_LEVEL(KK, SH)                                                                              \
-            {                                                                                         \
-                const hc_f32x4 P = pwc[4 * (KK)];                                                     \
-                const float u0 = hc_shr<SH>(sv[0]), u1 = hc_shr<SH>(sv[1]);                           \
-                const float u2 = hc_shr<SH>(sv[2]), u3 = hc_shr<SH>(sv[3]);                           \
-                sv[0] = fmaf(-P[1], u1, fmaf(P[0], u0, sv[0]));                                        \
-                sv[1] = fmaf(P[1], u0, fmaf(P[0], u1, sv[1]));                                         \
-                sv[2] = fmaf(-P[3], u3, fmaf(P[2], u2, sv[2]));                                        \
-                sv[3] = fmaf(P[3], u2, fmaf(P[2], u3, sv[3]));                                         \
+            // One Kogge-Stone level on the lane's two modes, (re, im) += P * (re, im) of the lane SH blocks to the left (0 beyond the
+            // row's start): the DPP shift is an operand of the FMA (v_fmac_f32_dpp) -- five instructions per mode and level instead of
+            // two DPP moves + four FMAs.  im' is built in a scratch register (the old im is still needed for re'), so the im registers
+            // alternate from level to level.  Wait states: a VGPR written by a VALU instruction may be read through DPP two
+            // instructions later at the earliest -- inside a level and from level to level the order below keeps that distance
+            // (hand-written: the compiler does not look into inline asm); the leading / trailing s_nop cover the compiler's own
+            // instructions around the block.
+#define HC_LEVEL(KK, SH, PRE, POST)                                                                                       \
+            {                                                                                                             \
+                const hc_f32x4 P = pwc[4 * (KK)];                                                                         \
+                float t1, t3;                                                                                             \
+                asm volatile(PRE                                                                                          \
+                             "v_mov_b32 %2, %4\n\t"                                                                       \
+                             "v_fmac_f32_dpp %2, %4, %6 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %2, %0, %7 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %0, %0, %6 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %0, %4, -%7 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+                             "v_mov_b32 %3, %5\n\t"                                                                       \
+                             "v_fmac_f32_dpp %3, %5, %8 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %3, %1, %9 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %1, %1, %8 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                             "v_fmac_f32_dpp %1, %5, -%9 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1" POST     \
+                             : "+v"(sv[0]), "+v"(sv[2]), "=&v"(t1), "=&v"(t3)                                             \
+                             : "v"(sv[1]), "v"(sv[3]), "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]));                       \
+                sv[1] = t1;                                                                                               \
+                sv[3] = t3;                                                                                               \
             }
-            HC_LEVEL(0, 1) HC_LEVEL(1, 2) HC_LEVEL(2, 4) HC_LEVEL(3, 8)
+            HC_LEVEL(0, 1, "s_nop 1\n\t", "") HC_LEVEL(1, 2, "", "") HC_LEVEL(2, 4, "", "") HC_LEVEL(3, 8, "", "\n\ts_nop 1")
 #undef HC_LEVEL
             float st[4];
 #pragma unroll
@@ -464,10 +497,27 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     // ---- the pipeline: one barrier per tile.  VM queue of a wave per interval, in issue order: HC_PPW DMA pieces of window(k + 1),
     //      HC_NST stores of tile k - 1; it retires in order, so before the barrier of interval k + 1 "window(k + 1) landed" is
     //      vmcnt(HC_NST) -- the stores may stay in flight.
+#if HC_PROFILE      // -DHC_PROFILE=1: every wave accumulates shader-clock deltas per phase and writes 16 floats at y + 64 B * (HC_NW * workgroup
+    //                 + wave) (tools/hc_stage_profile.py; a timing build: it overwrites y)
+    uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
+#define HC_STAMP(K) { const uint64_t now_ = __builtin_readcyclecounter(); tprof[K] += now_ - tlast; tlast = now_; }
+#else
+#define HC_STAMP(K)
+#endif
     Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
     if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
+#if HC_AHEAD == 2
+    if (n_steps > 1) { dma_win(c_dma, 1); advance(c_dma); }
+#endif
+#if HC_PROFILE
+    tlast = __builtin_readcyclecounter();
+#endif
     for (int k = 0; k <= n_steps; ++k) {
         const int buf = k & 1;
+        Cur nx = c_cmp;
+        advance(nx);
+        const bool next_row_start = nx.tile == 0;
         if (k < n_steps) {
             if (c_cmp.tile == 0 && wave == 0 && lane < 48) {  // a new row: its FIR history (or zeros) into this tile's halo slot
                 const int r = lane / 24, wq = lane - 24 * r; // 24 dwords per row: x2 | x1 | v
@@ -478,22 +528,56 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 }
                 *(uint32_t*)(smem + HC_OFF_HALO + buf * (2 * HC_ROWB) + r * HC_ROWB + wq * 4) = v;
             }
+#if HC_AHEAD == 2
+            // behind window(k) in the queue: stores(k - 3), the pieces of window(k + 1), stores(k - 2) -- all present in the steady state
+            if (k >= 3 && k + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_PPW + (SO ? 0 : 2 * HC_NST)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             if (!SO && k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
+        HC_STAMP(0);
         __syncthreads();                                     // window(k) and the halo slot -> everybody; staging(k - 1) complete
-        if (k + 1 < n_steps) { dma_win(c_dma, buf ^ 1); advance(c_dma); }
+        HC_STAMP(1);
+#if HC_AHEAD == 2
+        // two tiles in flight on two buffers: the window goes into registers at once, a second barrier says "everybody has read it",
+        // and the buffer is refilled with tile k + 2 while tile k + 1 is still landing in the other one
+        if (k < n_steps) read_win(buf, next_row_start);
+        HC_STAMP(5);
+        __syncthreads();
+        HC_STAMP(1);
+        if (k + 2 < n_steps) { dma_win(c_dma, buf); advance(c_dma); }
+        HC_STAMP(2);
         if (!SO && k >= 1) { store_tile(c_st, buf ^ 1); advance(c_st); }
+        HC_STAMP(3);
+#else
+        if (k + 1 < n_steps) { dma_win(c_dma, buf ^ 1); advance(c_dma); }
+        HC_STAMP(2);
+        if (!SO && k >= 1) { store_tile(c_st, buf ^ 1); advance(c_st); }
+        HC_STAMP(3);
+        if (k < n_steps) read_win(buf, next_row_start);
+        HC_STAMP(5);
+#endif
         if (k < n_steps) {
-            Cur nx = c_cmp;
-            advance(nx);
-            const bool next_row_start = nx.tile == 0;
-            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, next_row_start, hc_false{});
-            else compute(c_cmp, buf, next_row_start, hc_true{});
+            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, hc_false{});
+            else compute(c_cmp, buf, hc_true{});
             c_cmp = nx;
         }
+        HC_STAMP(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if HC_PROFILE
+    if (lane == 0) {
+        float* o = (float*)a.y + 16 * (blockIdx.x * HC_NW + wave);
+        for (int k = 0; k < 5; ++k) o[k] = (float)tprof[k];
+        o[8] = (float)tprof[5];
+        o[5] = (float)n_steps;
+        o[6] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);      // 100 MHz ticks, whole workgroup
+        o[7] = (float)(__builtin_readcyclecounter() - ck0);          // shader clocks, whole workgroup
+    }
+#endif
+#undef HC_STAMP
 }
 
 template <bool SO, bool WS>

@@ -398,13 +398,30 @@ class HipOps:
                               "apply": z.numel() * 2 + y.numel() * 2 + agg.numel() * 4}
         return y, state
 
+    def linear_zg_shape_ok(self, M: int, N: int, K: int) -> bool:
+        """Shape part of linear_zg_ok (a pure function of the sizes: sequence-parallel ranks evaluate it on the SAME numbers)."""
+        return (self.hyena_zg and M >= 256 and N % 256 == 0 and N % 48 == 0 and N < 65536 and K % 64 == 0 and K >= 128
+                and M * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and M * N * 2 < 0xfffffff0)
+
     def linear_zg_ok(self, x: torch.Tensor, w: torch.Tensor) -> bool:
         """The projection of a Hyena block as a dense layer with a GROUP-MAJOR result (csrc/gemm.hip, mode 2)."""
         M, K = x.shape
         N = w.shape[0]
-        return (self.hyena_zg and M >= 256 and N % 256 == 0 and N % 48 == 0 and N < 65536 and K % 64 == 0 and K >= 128
-                and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous()
-                and M * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and M * N * 2 < 0xfffffff0)
+        return (self.linear_zg_shape_ok(M, N, K)
+                and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous())
+
+    @staticmethod
+    def zg_rows(zg: torch.Tensor, B: int, T: int, t0: int, n: int) -> torch.Tensor:
+        """Rows t0 .. t0 + n - 1 of every batch row of a group-major z [G, B T, 48] as token-major [B, n, 3 D] (grouped column order)."""
+        G = zg.shape[0]
+        return zg.view(G, B, T, 48)[:, :, t0:t0 + n, :].permute(1, 2, 0, 3).reshape(B, n, G * 48)
+
+    @staticmethod
+    def zg_set_rows(zg: torch.Tensor, B: int, T: int, t0: int, rows: torch.Tensor) -> None:
+        """The inverse: write token-major rows [B, n, 3 D] (grouped column order) into rows t0 .. of every batch row of zg."""
+        G = zg.shape[0]
+        n = rows.shape[1]
+        zg.view(G, B, T, 48)[:, :, t0:t0 + n, :] = rows.view(B, n, G, 48).permute(2, 0, 1, 3)
 
     def linear_zg(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
         """z [N / 48, M, 48] bf16 = x [M, K] @ w[N, K]^T (+ b), the columns of w in the grouped order of the single-pass Hyena

@@ -364,15 +364,28 @@ class StripedHyena(nn.Module):
                     z3 = ops.linear(n1, wg, bg).view(B, T, 3 * D)
                     y = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H).view(B * T, D)
             else:
-                z3 = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, wg, bg).view(B, T, 3 * D)
                 halo = s0 = None
                 if have_state:                  # continue a cached prefix with more than one token
                     halo = cache.fir_state_dict[i].transpose(1, 2)[..., perm].contiguous()
                     s0 = cache.state_dict[i]
-                y3, state = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H, halo, s0=s0,
-                                                   want_state=True, poles=f._poles)
+                n1 = None
+                if hasattr(ops, "hyena_cs") and getattr(ops, "hyena_zg", False):
+                    n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
+                if n1 is not None and ops.linear_zg_ok(n1, wg):
+                    # cached prefill on GROUP-MAJOR z too (round 4): the same projection launch and the same operator kernel as
+                    # scoring, plus the carried state in / the end state out
+                    zg = ops.linear_zg(n1, wg, bg)
+                    y3, state = ops.hyena_cs(zg, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
+                                             want_state=True, poles=f._poles)
+                    tail = ops.zg_rows(zg, B, T, T - K1, K1)
+                else:
+                    z3 = (ops.linear(n1, wg, bg) if n1 is not None
+                          else ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, wg, bg)).view(B, T, 3 * D)
+                    y3, state = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H, halo, s0=s0,
+                                                       want_state=True, poles=f._poles)
+                    tail = z3[:, -K1:, :]
                 y = y3.view(B * T, D)
-                cache.fir_state_dict[i] = z3[:, -K1:, :][..., inv].transpose(1, 2).contiguous()      # [B, 3D, 2], reference order
+                cache.fir_state_dict[i] = tail[..., inv].transpose(1, 2).contiguous()      # [B, 3D, 2], reference order
                 cache.state_dict[i] = state
         else:
             z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]

@@ -307,12 +307,23 @@ class SequenceParallelScorer:
                 halo, halo_w = self._shift(tail)
             else:                                            # (last rank only, see check_geometry: nobody reads it)
                 halo, halo_w = self._shift(n1.new_zeros(B, 2, 3 * D))
-        z = ops.linear(n1, w_p, b_p).view(B, Tloc, 3 * D)
+        # round 4: the fast path hands the operator its input GROUP-MAJOR ([D / 16][B Tloc][48], written that way by the projection's
+        # dense layer, as in scoring) and runs both stages on the channel-stationary kernel; the verdict is a function of
+        # (B, Tl, world) only -- evaluated on the longest shard, the same on every rank
+        zgm = fast and hasattr(ops, "hyena_cs") and ops.linear_zg_shape_ok(B * Tl, 3 * D, D) \
+            and ops.linear_zg_shape_ok(B * t_min, 3 * D, D)
+        if zgm:
+            z = ops.linear_zg(n1, w_p, b_p)                  # [D / 16, B Tloc, 48]
+        else:
+            z = ops.linear(n1, w_p, b_p).view(B, Tloc, 3 * D)
         if tail is not None:
             # the two rows the next rank convolves with came out of the weight-streaming kernel, this rank's own copy of them
             # out of the tile GEMM (another summation order: up to one bf16 ulp apart) -- use the SENT values here too, so
             # that both sides of a shard boundary see the same z
-            z[:, -2:, :] = tail
+            if zgm:
+                ops.zg_set_rows(z, B, Tloc, Tloc - 2, tail)
+            else:
+                z[:, -2:, :] = tail
         halo_w.wait()
         if halo is not None:
             halo = halo.contiguous()
@@ -323,13 +334,16 @@ class SequenceParallelScorer:
         for g in range(G):
             b0, b1 = bounds[g], bounds[g + 1]
             hg = halo[b0:b1] if halo is not None else None
-            if fast:
+            if zgm:
+                e_r = ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, poles=f._poles,
+                                   state_only=True, row0=b0 * Tloc)
+            elif fast:
                 e_r = ops.hyena_mfma_state(z[b0:b1], f._fir_w, f.short_filter_bias, table, H, f._poles, z_halo=hg)
             else:
                 st1[g], e_r = ops.hyena_stage1(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, H, z_halo=hg)
             ends[g], works[g] = self._gather0(torch.view_as_real(e_r.to(torch.complex64)), async_op=True,
                                               name="state_allgather")
-        y = torch.empty(B, Tloc, D, dtype=z.dtype, device=z.device) if G > 1 else None
+        y = torch.empty(B, Tloc, D, dtype=torch.bfloat16 if zgm else z.dtype, device=z.device) if G > 1 else None
         for g in range(G):
             b0, b1 = bounds[g], bounds[g + 1]
             works[g].wait()
@@ -340,7 +354,9 @@ class SequenceParallelScorer:
                 idx = torch.arange(self.rank - 1, -1, -1, device=e.device)         # exponent index r-1-q
                 s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
             hg = halo[b0:b1] if halo is not None else None
-            if fast:
+            if zgm:
+                yg = ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, s0=s0, row0=b0 * Tloc)
+            elif fast:
                 yg = ops.hyena_mfma_prefill(z[b0:b1], f._fir_w, f.short_filter_bias, f.D, table, H, hg, s0=s0)
             else:
                 yg = ops.hyena_stage2(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1[g],

@@ -124,11 +124,13 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
     attn_idx = set(FULL_131K["attn_layer_idxs"])
     o = _gpu_oracle(full, "fp32")
     oc = o.initialize_inference_params()
+    ob = _gpu_oracle(full, "bf16")                              # the reference's own eager-bf16 arithmetic: the floor for the caches
+    obc = ob.initialize_inference_params()
 
     # ---- every block teacher-forced, WITH the oracle's caches: the prompt pass, then every decode step -------------------
     t0 = time.time()
     worst = {"hyena": [0.0, 0.0, 0.0], "attn": [0.0, 0.0, 0.0]}
-    state_rel = fir_max = kv_rel = 0.0
+    state_rel = state_floor = fir_max = kv_rel = 0.0
     bad = []                                                   # (every measurement is printed before anything is asserted)
     for i in range(32):
         kind = "attn" if i in attn_idx else "hyena"
@@ -141,7 +143,10 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
             bad.append(("prompt", i, kind, err, hu, upd))
         if kind == "hyena":                                    # what the prompt pass leaves in the caches (same block input)
             se, sr = cache["state"][i].to(torch.complex128), oc["hyena"].state_dict[i].to(torch.complex128)
-            state_rel = max(state_rel, ((se - sr).abs().max() / sr.abs().max()).item())
+            ob.hyena_block(u.bfloat16(), i, obc["hyena"])
+            sf = obc["hyena"].state_dict[i].to(torch.complex128)
+            state_rel = max(state_rel, ((se - sr).norm() / sr.norm()).item())
+            state_floor = max(state_floor, ((sf - sr).norm() / sr.norm()).item())
             fe, fr = cache["fir"][i].double(), oc["hyena"].fir_state_dict[i].double()
             fir_max = max(fir_max, ((fe - fr).abs() / (fr.abs() * 2.0 ** -8 + fr.abs().max() * 2e-3)).max().item())
         else:
@@ -151,7 +156,7 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
         del ref, got, u
     print(f"[configs4 prompt pass, 8192 tokens, teacher-forced + cached] worst Hyena block: output rel-L2 {worst['hyena'][0]:.3e}, "
           f"half-ulps {worst['hyena'][1]:.1f}, update {worst['hyena'][2]:.3e}; attention: {worst['attn'][0]:.3e}, {worst['attn'][1]:.1f}, "
-          f"{worst['attn'][2]:.3e}; modal end state rel {state_rel:.2e}, FIR history worst / (2^-8|ref| + 2e-3 max) {fir_max:.2f}, "
+          f"{worst['attn'][2]:.3e}; modal end state rel-L2 {state_rel:.2e} (eager-bf16 oracle block: {state_floor:.2e}), FIR history worst / (2^-8|ref| + 2e-3 max) {fir_max:.2f}, "
           f"K/V rows rel-L2 {kv_rel:.2e}  ({time.time() - t0:.1f} s)")
     # the end state sums 8,192 bf16-rounded inputs: the reference's own eager-bf16 arithmetic sits at 2.8e-3 (tests/PARITY.md (e))
     t0 = time.time()
@@ -172,7 +177,8 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
           f"{wstep['attn'][0]:.3e}, {wstep['attn'][1]:.1f}, {wstep['attn'][2]:.3e}  ({time.time() - t0:.1f} s)")
     del taps, oc
     assert not bad, bad[:12]
-    assert state_rel <= 6e-3 and fir_max <= 1.0 and kv_rel <= 4e-3, (state_rel, fir_max, kv_rel)
+    # the end state sums 8,192 inputs x1 * v that carry the bf16 rounding of z: judged against what the reference's own arithmetic does
+    assert state_rel <= max(1.25 * state_floor, 4e-3) and fir_max <= 1.0 and kv_rel <= 4e-3, (state_rel, state_floor, fir_max, kv_rel)
 
     # ---- end to end: the oracle's own cached path, fed the engine's tokens; the eager-bf16 restatement beside it ---------------
     def oracle_run(orc):
@@ -226,16 +232,17 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     ops = m.ops
     comm = _ThreadComm(world)
     rec = {r: [] for r in range(world)}                       # per rank: (z as the kernel got it, z_halo, s0, y) of Hyena layer 0
-    real_prefill = ops.hyena_mfma_prefill
+    real_cs = ops.hyena_cs
 
-    def spy(z, *a, **kw):
-        y = real_prefill(z, *a, **kw)
+    def spy(zg, nb, tl, *a, **kw):
+        out = real_cs(zg, nb, tl, *a, **kw)
         r = comm.local.rank
-        if len(rec[r]) < 2:                                   # layer 0 = the first two calls of a rank (two row groups of one row)
-            halo = a[5] if len(a) > 5 else kw.get("z_halo")
-            rec[r].append((z.clone(), None if halo is None else halo.clone(), kw.get("s0"), (y[0] if isinstance(y, tuple) else y).clone(),
-                           kw.get("zg_shape")))
-        return y
+        if not kw.get("state_only", False) and len(rec[r]) < 2:        # layer 0 = the first two output launches of a rank (two row groups)
+            row0 = kw.get("row0", 0)
+            zt = ops.zg_rows(zg[:, row0:row0 + nb * tl, :], nb, tl, 0, tl).clone()        # token-major [nb, tl, 3 D], grouped column order
+            halo = kw.get("z_halo")
+            rec[r].append((zt, None if halo is None else halo.clone(), kw.get("s0"), (out[0] if isinstance(out, tuple) else out).clone()))
+        return out
 
     outs, errs = [None] * world, []
 
@@ -252,13 +259,13 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
             errs.append(e)
             comm.bar.abort()
 
-    ops.hyena_mfma_prefill = spy
+    ops.hyena_cs = spy
     try:
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         [t.start() for t in th]
         [t.join(900) for t in th]
     finally:
-        del ops.hyena_mfma_prefill                             # (the instance attribute shadowed the method)
+        del ops.hyena_cs                                       # (the instance attribute shadowed the method)
     assert not errs, errs
     Tl = outs[0][0][0]
     assert Tl == 16385 and [o[0][2] - o[0][1] for o in outs] == [16385] * 7 + [16378]
@@ -270,38 +277,32 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     want = logits_to_logprobs(full_logits.float().cpu(), ids.cpu(), trim_bos=True).double()
     assert lp.shape == want.shape
     dlp, dscore = (lp - want).abs().mean().item(), (abs(lp.mean() - want.mean()) / abs(want.mean())).item()
-    # the yardstick at THESE dimensions: the unsharded forward once more with every dense layer on the other kernel routing
-    # (all hand-written): the same arithmetic in another tiling / summation order -- what "bf16 noise of another tiling
-    # through 4 blocks" amounts to at D = 4096 (the toy models of the two-process test measure 4.5e-3)
-    was = ops.all_gemm_mfma
-    ops.all_gemm_mfma = not was
+    # the yardstick at THESE dimensions: the unsharded forward once more with the Hyena operator on its other kernels (the modal
+    # three-launch form: the same operator to fp32 rounding, i.e. a few per cent of the bf16 outputs of every Hyena layer land on
+    # the other side of a rounding boundary) -- exactly the perturbation a carried-in state is: what it grows to through the
+    # remaining layers is "bf16 noise of another evaluation order" at D = 4096 (the toy models of the two-process test: 4.5e-3)
+    was = ops.hyena_mfma
+    ops.hyena_mfma = False
     try:
         with torch.inference_mode():
             other = m(ids)[0]
     finally:
-        ops.all_gemm_mfma = was
+        ops.hyena_mfma = was
     noise = rel_l2(other, full_logits)
     noise_shards = [rel_l2(other[:, o[0][1]:o[0][2]], full_logits[:, o[0][1]:o[0][2]]) for o in outs]
     del other
     print(f"[configs3, 8 virtual ranks x 16,385 tokens, D = 4096, 4 layers] sharded vs unsharded HIP forward: logits rel-L2 {err:.3e} "
           f"(per shard {' '.join(f'{x:.2e}' for x in per_shard)}), mean |d logprob| {dlp:.2e}, score rel {dscore:.2e}; "
-          f"tiling-noise yardstick (unsharded, other dense-layer routing): {noise:.3e} (per shard {' '.join(f'{x:.2e}' for x in noise_shards)})")
-    # shard 0 has no carry-in, no halo and sees only its own keys: its distance is tiling noise alone; the other shards add
-    # the fp32 carry / pole-power arithmetic, which must not show at this scale
-    sharded_ok = err <= max(1.5 * noise, 8e-3) and max(per_shard) <= max(1.5 * max(noise_shards), 1.5 * per_shard[0], 1.2e-2)
+          f"evaluation-order yardstick (unsharded forward, modal Hyena kernels): {noise:.3e} (per shard {' '.join(f'{x:.2e}' for x in noise_shards)})")
+    # shard 0 has no carry-in and no halo and sees only its own keys: (almost) the unsharded arithmetic; the other shards add the
+    # fp32 carry / pole-power arithmetic, which must not show beyond the yardstick
+    sharded_ok = err <= max(1.5 * noise, 8e-3) and max(per_shard) <= max(1.5 * max(noise_shards), 1.2e-2)
     assert dlp < 5e-2 and dscore < 3e-3
 
     # ---- shard 7's Hyena output of layer 0 (carry from 7 predecessors) vs the fp64 FFT long convolution over the WHOLE sequence
     assert all(len(rec[r]) == 2 for r in range(world)), {r: len(v) for r, v in rec.items()}
     _, _, _, perm, inv = m._mfma_pack(m.blocks[0])
     f = m.blocks[0].filter
-
-    def token_major(z, zg_shape, nrows):
-        """what the kernel was handed -> [rows, Tloc, 3 D] in the REFERENCE column order"""
-        if zg_shape is not None:                               # group-major [D/16][rows * Tloc][48]
-            nb, tl = zg_shape
-            z = z.view(D // 16, nb, tl, 48).permute(1, 2, 0, 3).reshape(nb, tl, 3 * D)
-        return z[..., inv]
 
     heads = [0, 13, 31]
     cols = torch.cat([torch.arange(h * 384, (h + 1) * 384) for h in heads]).to(DEV)
@@ -310,7 +311,7 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     t0 = time.time()
     worst_rl2 = worst_ex = 0.0
     for b in range(B):
-        zfull = torch.cat([token_major(rec[r][b][0], rec[r][b][4], 1)[0][:, cols] for r in range(world)], 0)     # [T, 3 * 384]
+        zfull = torch.cat([rec[r][b][0][0][..., inv][:, cols] for r in range(world)], 0)          # [T, 3 * 384], reference column order
         assert zfull.shape == (T, 3 * 384)
         ry, _ = gpu_fft_hyena(zfull[None], f._fir_w[cols], f.short_filter_bias.data[cols], f._poles[chans], f._residues[chans],
                               f.D.data[chans], len(heads), want_state=False)
