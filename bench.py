@@ -192,7 +192,7 @@ def cpu_baseline(model=None, nt=512):
                "sample": f"oracle fp32 mode (bf16-rounded weights), the full 32-block evo-1-8k-base forward on 1 x {nt} nt "
                          f"(BASELINE configs[0]), one timed pass", "seconds": dt, "score": score}
         try:
-            out["legs"] = cpu_baseline_legs(m, R)
+            out["legs"] = cpu_baseline_legs(m, R, engine=model)
         except Exception as e:  # noqa: BLE001   (the extra legs never take the headline baseline down with them)
             out["legs"] = {"error": f"{type(e).__name__}: {e}"}
         return out
@@ -214,7 +214,7 @@ def cpu_baseline(model=None, nt=512):
             "seconds_per_4_blocks": dt}
 
 
-def cpu_baseline_legs(m, R):
+def cpu_baseline_legs(m, R, engine=None):
     """BASELINE.md section 2, configs[1], [2], [4] on the host cores -- bounded samples of the same oracle on the same weights
     (the full passes are ~107 TFLOP and ~2.1 PFLOP of fp32 on a host), every extrapolation labelled:
       configs[1]  B = 1, T = 8,193: blocks 0-2 (Hyena) and 8 (attention) at full width, timed; the pass = 29 x mean(Hyena
@@ -288,16 +288,34 @@ def cpu_baseline_legs(m, R):
         ipd["hyena"].seqlen_offset = ids.shape[1]
         tok = logits[:, -1].argmax(-1, keepdim=True)
         n_dec = 32
+        o_toks, o_logits = [tok], [logits[0, -1].float()]
         t0 = time.perf_counter()
         for _ in range(n_dec):
             logits, ipd = m(tok, ipd)
             ipd["mha"].seqlen_offset += 1
             ipd["hyena"].seqlen_offset += 1
             tok = logits[:, -1].argmax(-1, keepdim=True)
+            o_toks.append(tok)
+            o_logits.append(logits[0, -1].float())
         dt = time.perf_counter() - t0
         legs["configs4"] = {"value": n_dec / dt, "unit": "tok/s", "cores": torch.get_num_threads(), "kind": "port",
                             "sample": "128-token prefill, then 32 greedy recurrent decode steps (Hyena modal state + FIR state + KV cache), "
                                       "batch 1, fp32", "ms_per_token": 1e3 * dt / n_dec}
+        if engine is not None:
+            # the engine on the same prompt through its cached path (prefill, eager first step, hipGraph replays), fed the ORACLE's
+            # tokens so that one flipped argmax does not cascade: do the two agree on what they would have sampled?
+            dev = engine.device
+            c = engine.initialize_inference_params()
+            e_logits = [engine(ids.to(dev), c)[0][0, -1].float().cpu()]
+            for j in range(n_dec):
+                c["mha"].seqlen_offset = c["hyena"].seqlen_offset = ids.shape[1] + j
+                e_logits.append(engine(o_toks[j].to(dev), c)[0][0, -1].float().cpu())
+            if hasattr(engine, "release_decode_graph"):
+                engine.release_decode_graph()
+            el, ol = torch.stack(e_logits), torch.stack(o_logits)
+            legs["configs4"]["tokens_agree"] = float((el.argmax(-1) == ol.argmax(-1)).float().mean())
+            legs["configs4"]["gpu_logits_rel_l2_same_tokens"] = float((el.double() - ol.double()).norm() / ol.double().norm())
+            legs["configs4"]["tokens_compared"] = n_dec + 1
     return legs
 
 
@@ -329,6 +347,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nt", type=int, default=8192)
     ap.add_argument("--skip-131k", action="store_true")
+    ap.add_argument("--skip-sp-predict", action="store_true", help="skip the stub-communicator rank of configs[3] (scaling_131k_predicted)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-gen", action="store_true")
     ap.add_argument("--steps-131k", type=int, default=2)
@@ -519,6 +538,8 @@ def main():
 
     if n_gpus > 1 and "ctx131k" in out and "error" not in out["ctx131k"]:
         out["scaling_131k"] = out["ctx131k"].get("scaling")   # BASELINE configs[3]: the sequence-split result, top level
+    if n_gpus == 1 and isinstance(out.get("ctx131k"), dict) and "scaling_131k_predicted" in out["ctx131k"]:
+        out["scaling_131k_predicted"] = out["ctx131k"].pop("scaling_131k_predicted")
     if rank == 0:
         print(json.dumps(out))
     if dist_on:
@@ -654,6 +675,16 @@ def bench_131k(args, device, rank, world, dist_on, ops):
            "kernels": {k: {"launches": v[0], "avg_ms": v[1]} for k, v in ks.items()}}
     if scaling is not None:
         res["scaling"] = scaling
+    if world == 1 and not getattr(args, "skip_sp_predict", False):
+        # BASELINE configs[3] cannot run on this pool (one GPU per box): one rank's kernels behind a stub communicator give the
+        # per-rank compute time and, with stated link assumptions, a predicted 8-GPU rate (tools/sp_predict.py)
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            from sp_predict import sp_predict
+            res["scaling_131k_predicted"] = sp_predict(model, device, ops, single_ms=per * 1e3, acgt_ids=acgt_ids,
+                                                       scoring_step=scoring_step)
+        except Exception as e:  # noqa: BLE001
+            res["scaling_131k_predicted"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and "attn_fwd" in ks:
         fl = 4 * D * T * T / 2
         res["kernels"]["attn_fwd"]["tflops"] = fl / (ks["attn_fwd"][1] * 1e-3) / 1e12

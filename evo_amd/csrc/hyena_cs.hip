@@ -61,9 +61,6 @@ static_assert(HC_LDS <= 160 * 1024, "LDS");
 #ifndef HC_PROFILE
 #define HC_PROFILE 0
 #endif
-#ifndef HC_AHEAD
-#define HC_AHEAD 2                          // window tiles in flight: 2 (two barriers per tile, the buffer refilled as soon as it is in registers) | 1
-#endif
 #define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
 
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
@@ -191,25 +188,38 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         const int blk = o / HC_BLKB, within = o - HC_BLKB * blk;
         dma_off[i] = (uint32_t)(32 * HC_ROWB * blk + (within < 32 * HC_ROWB ? within : 32 * HC_ROWB - 16));
     }
-    auto dma_win = [&](const Cur& c, int buf) {
+    // The pieces of a window are NOT issued in a burst: the CU issues one 1 KiB LDS-DMA piece per ~60 clocks, so the 49 pieces of
+    // a tile behind a barrier keep the last wave waiting ~2.9 k clocks at the vector-memory queue before it computes anything
+    // (tools/hc_stage_profile.py, round 4: per tile 8.4 k clocks = 2.9 k DMA issue + 0.6 k stores + 1.1 k window reads + 3.5 k
+    // compute, one after the other).  `vm_prepare` builds the tile's descriptor, `vm_piece` issues ONE piece; `compute` calls it
+    // at points spread over the tile's arithmetic, so that a wave's memory instructions queue while its partner on the SIMD computes.
+    struct Vm { hc_srd d; uint32_t base; bool dma; bool st; Cur cst; int sbuf; };
+    auto vm_prepare = [&](Vm& v, const Cur& c, int buf) {
         // descriptor of this tile of the (group, batch row) stream: base = first row of the tile, num_records = bytes up to the
         // end of the row's T tokens (the hardware returns zeros beyond: the ragged last tile needs no clamping)
         const int64_t row0 = (int64_t)cg * a.z_group_rows + (int64_t)c.b * Ti + (int64_t)c.tile * HC_TT;
         const uint64_t a64 = (uint64_t)(a.z + row0 * HC_ROWB);
         const int64_t left = ((int64_t)Ti - (int64_t)c.tile * HC_TT) * HC_ROWB;
-        hc_srd d;
-        d[0] = (int)(uint32_t)a64;
-        d[1] = (int)(uint32_t)(a64 >> 32);
-        d[2] = (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0);
-        d[3] = 0x00020000;
-        const uint32_t base = lds0 + HC_OFF_WIN + buf * HC_WINB;
+        v.d[0] = (int)(uint32_t)a64;
+        v.d[1] = (int)(uint32_t)(a64 >> 32);
+        // (no next tile: num_records = 0 -- the pieces are still issued, as zeros into the free buffer, so that every interval
+        //  carries the same instructions: no branch around a piece, constant vmcnt arithmetic)
+        v.d[2] = (int)(v.dma && left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0);
+        v.d[3] = 0x00020000;
+        v.base = lds0 + HC_OFF_WIN + buf * HC_WINB;
+    };
+    auto vm_piece = [&](const Vm& v, const int i) {
+        int p = wave + HC_NW * i;
+        p = p < HC_NPIECE ? p : HC_NPIECE - 1;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     ::"s"(v.base + 1024 * p), "v"(dma_off[i]), "s"(v.d) : "memory", "m0");
+    };
+    auto dma_win = [&](const Cur& c, int buf) {              // (the whole window at once: prologue only)
+        Vm v;
+        v.dma = true;
+        vm_prepare(v, c, buf);
 #pragma unroll
-        for (int i = 0; i < HC_PPW; ++i) {
-            int p = wave + HC_NW * i;
-            p = p < HC_NPIECE ? p : HC_NPIECE - 1;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                         ::"s"(base + 1024 * p), "v"(dma_off[i]), "s"(d) : "memory", "m0");
-        }
+        for (int i = 0; i < HC_PPW; ++i) vm_piece(v, i);
     };
 
     // ---- per-lane LDS addresses (buffer 0; + HC_WINB / + HC_STGB / + 192 for buffer 1)
@@ -228,23 +238,23 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     const float first_blk = la == 0 ? 1.f : 0.f;
 
     // ---- store of tile `c` from staging buffer `buf`: the wave's HC_RW rows x 32 B, 16 B per lane
-    auto store_tile = [&](const Cur& c, int buf) {
+    auto vm_store = [&](const Vm& v, const int hs) {
+        if (SO) return;
+        const Cur& c = v.cst;
         const int t0 = c.tile * HC_TT;
         const bool full = t0 + HC_TT <= Ti;
         const uint32_t row0 = (uint32_t)(((int64_t)c.b * Ti + t0) * a.y_rowbytes + d0 * 2);
-#pragma unroll
-        for (int hs = 0; hs < HC_NST; ++hs) {
-            const int row = HC_RW * wave + 32 * hs + (lane >> 1);
-            const hc_u32x4 v = *(const hc_u32x4*)(smem + HC_OFF_STG + buf * HC_STGB + row * 32 + (row >> 5) * 16 + (lane & 1) * 16);
-            // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
-            // counter sees exactly HC_NST stores per interval
-            const uint32_t off = (full || t0 + row < Ti) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(ysrd) : "memory");
-        }
+        const int row = HC_RW * wave + 32 * hs + (lane >> 1);
+        const hc_u32x4 val = *(const hc_u32x4*)(smem + HC_OFF_STG + v.sbuf * HC_STGB + row * 32 + (row >> 5) * 16 + (lane & 1) * 16);
+        // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
+        // counter sees exactly HC_NST stores per interval
+        // (also dropped that way: the stores of the first interval, which has no previous tile)
+        const uint32_t off = (v.st && (full || t0 + row < Ti)) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(val), "v"(off), "s"(ysrd) : "memory");
     };
 
-    // ---- the window of a tile into registers: ten rows (two of history) x three signals, 8 bytes = 4 channels each -- ALL reads
-    //      first, one LDS round trip; then the window buffer is free again (HC_AHEAD = 2: it is refilled right away)
+    // ---- the window of a tile into registers: ten rows (two of history) x three signals, 8 bytes = 4 channels each (the compiler
+    //      places the waits where the values are used: the FIR of v and x1 starts while the x2 rows are still on their way)
     constexpr int NQ = HC_CPW == 4 ? 2 : 1;                  // dwords per read
     uint32_t raw[3][10][NQ];
     auto read_win = [&](int buf, bool next_row_start) {
@@ -259,13 +269,6 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; raw[g][i][0] = v[0]; raw[g][i][NQ - 1] = v[1]; }
                 else raw[g][i][0] = *(const uint32_t*)p;
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int i = 0; i < 10; ++i)
-#pragma unroll
-                for (int e = 0; e < NQ; ++e) asm volatile("" : "+v"(raw[g][i][e]));            // (kept as loaded: no re-read behind the barrier)
         // rows 510, 511 of this tile are the history of the next one: lane 63 holds them (its rows 8, 9)
         if (lane == 63 && !next_row_start) {
             unsigned char* hp = smem + HC_OFF_HALO + (buf ^ 1) * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
@@ -280,7 +283,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     };
 
     // ---- one tile of this wave's channels, from the registers read_win filled
-    auto compute = [&](const Cur& c, int buf, auto ragged_t) {
+    auto compute = [&](const Cur& c, int buf, const Vm& vm, auto ragged_t) {
         constexpr bool RAGGED = decltype(ragged_t)::value;
         const int t0 = c.tile * HC_TT;
         const bool last_tile = c.tile == a.n_tiles - 1;
@@ -297,6 +300,8 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
             }
         }
         const int n_valid = RAGGED ? Ti - (t0 + 32 * la + 8 * lq) : 8;         // steps of this lane inside the sequence
+        static_assert(HC_PPW == 1 + 2 * HC_NPAIR + 2 * HC_CPW && HC_NST == HC_CPW, "issue points of the window pieces / stores");
+        vm_piece(vm, 0);
 
         bf16x8_t xh[HC_CPW];
 #if HC_XLO
@@ -322,6 +327,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     m2a = m1a; m1a = ca; m2b = m1b; m1b = cb;
                 }
             }
+            vm_piece(vm, 1 + 2 * pp);
             if (!SO) {
                 const f32x2_t* fp_ = fwl + pp * 12;
                 const f32x2_t w00 = fp_[0], w01 = fp_[1], w02 = fp_[2], b0f = fp_[3];
@@ -333,6 +339,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     m2 = m1; m1 = cx;
                 }
             }
+            vm_piece(vm, 2 + 2 * pp);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 uint32_t hw[4];
@@ -375,6 +382,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     yv[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(8 * mt), xh[cc], acc, 0, 0, 0);
                 }
             HC_FENCE_NOP();
+            vm_piece(vm, 1 + 2 * HC_NPAIR + 2 * cc);
             // Kogge-Stone scan of the 16 block aggregates -> state entering every block; the tile's end state
             float sv[4] = {e[0], e[1], e[2], e[3]};
             const hc_f32x4* pwc = (const hc_f32x4*)(pwl + (ch0 + cc) * 64) + lq;
@@ -421,6 +429,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[r]), 0x121, 0xf, 0xf, false));
+            vm_piece(vm, 2 + 2 * HC_NPAIR + 2 * cc);
             if (WS && last_tile) {
                 // state after the last token T - 1, which sits in block a_ at local step r_ - 1: the recurrence over the block's first
                 // r_ steps from the state entering it.  Lane s (< 8) takes mode s.  The x values are the very bf16 terms the matrix
@@ -477,6 +486,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 }
                 HC_FENCE_NOP();
             }
+            vm_store(vm, cc);                                // (tile k - 1, staged before the barrier; one 16-byte store per lane)
 #undef HC_FRAG
         }
         // ---- gate and stage: accumulator (mt, r) of a lane is its step 4 mt + r; one dword (two channels) per step and pair
@@ -494,9 +504,9 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         }
     };
 
-    // ---- the pipeline: one barrier per tile.  VM queue of a wave per interval, in issue order: HC_PPW DMA pieces of window(k + 1),
-    //      HC_NST stores of tile k - 1; it retires in order, so before the barrier of interval k + 1 "window(k + 1) landed" is
-    //      vmcnt(HC_NST) -- the stores may stay in flight.
+    // ---- the pipeline: one barrier per tile.  VM queue of a wave per interval, in issue order: the HC_PPW pieces of window(k + 1) and
+    //      the HC_NST stores of tile k - 1, interleaved with the arithmetic; the LAST memory instruction of an interval is a store and
+    //      the last piece precedes it directly, so before the barrier of interval k + 1 "window(k + 1) landed" is vmcnt(1).
 #if HC_PROFILE      // -DHC_PROFILE=1: every wave accumulates shader-clock deltas per phase and writes 16 floats at y + 64 B * (HC_NW * workgroup
     //                 + wave) (tools/hc_stage_profile.py; a timing build: it overwrites y)
     uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -507,9 +517,6 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #endif
     Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
     if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
-#if HC_AHEAD == 2
-    if (n_steps > 1) { dma_win(c_dma, 1); advance(c_dma); }
-#endif
 #if HC_PROFILE
     tlast = __builtin_readcyclecounter();
 #endif
@@ -528,41 +535,30 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 }
                 *(uint32_t*)(smem + HC_OFF_HALO + buf * (2 * HC_ROWB) + r * HC_ROWB + wq * 4) = v;
             }
-#if HC_AHEAD == 2
-            // behind window(k) in the queue: stores(k - 3), the pieces of window(k + 1), stores(k - 2) -- all present in the steady state
-            if (k >= 3 && k + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_PPW + (SO ? 0 : 2 * HC_NST)) : "memory");
+            // interval k - 1 issued, in this order: ..., the last piece of window(k), ONE more store (of tile k - 2; dropped when k = 1)
+            if (!SO && k >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            if (!SO && k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_NST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         }
         HC_STAMP(0);
         __syncthreads();                                     // window(k) and the halo slot -> everybody; staging(k - 1) complete
         HC_STAMP(1);
-#if HC_AHEAD == 2
-        // two tiles in flight on two buffers: the window goes into registers at once, a second barrier says "everybody has read it",
-        // and the buffer is refilled with tile k + 2 while tile k + 1 is still landing in the other one
-        if (k < n_steps) read_win(buf, next_row_start);
-        HC_STAMP(5);
-        __syncthreads();
-        HC_STAMP(1);
-        if (k + 2 < n_steps) { dma_win(c_dma, buf); advance(c_dma); }
-        HC_STAMP(2);
-        if (!SO && k >= 1) { store_tile(c_st, buf ^ 1); advance(c_st); }
-        HC_STAMP(3);
-#else
-        if (k + 1 < n_steps) { dma_win(c_dma, buf ^ 1); advance(c_dma); }
-        HC_STAMP(2);
-        if (!SO && k >= 1) { store_tile(c_st, buf ^ 1); advance(c_st); }
-        HC_STAMP(3);
-        if (k < n_steps) read_win(buf, next_row_start);
-        HC_STAMP(5);
-#endif
+        Vm vm;
+        vm.dma = k + 1 < n_steps;
+        vm_prepare(vm, c_dma, buf ^ 1);
+        if (vm.dma) advance(c_dma);
+        vm.st = !SO && k >= 1;
+        vm.cst = c_st;
+        vm.sbuf = buf ^ 1;
+        if (vm.st) advance(c_st);
         if (k < n_steps) {
-            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, hc_false{});
-            else compute(c_cmp, buf, hc_true{});
+            read_win(buf, next_row_start);
+            HC_STAMP(5);
+            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, vm, hc_false{});
+            else compute(c_cmp, buf, vm, hc_true{});
             c_cmp = nx;
+        } else {
+#pragma unroll
+            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);      // the last tile's outputs
         }
         HC_STAMP(4);
     }

@@ -168,6 +168,39 @@ class HostStagedComm:
         return out, h
 
 
+class StubComm:
+    """NOT a data path: a communicator whose exchanges return resident buffers of the right shape at once (what this rank sent
+    stands in for what it would receive).  `SequenceParallelScorer(model, rank, world, comm=StubComm(world))` then executes exactly
+    the kernels one rank of a `world`-rank job executes -- same shard length, same row groups, the carried-state arithmetic, Ulysses
+    attention over the full sequence for H / world heads -- on ONE GPU: the per-rank compute time behind bench.py's
+    `scaling_131k_predicted` (tools/sp_predict.py).  The values it produces mean nothing."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self._g = {}
+        self.bytes = {"all_gather": 0, "all_to_all": 0, "shift": 0}      # what a real communicator would have received, per call site
+
+    def all_gather(self, t, async_op=False):
+        key = (tuple(t.shape), t.dtype)
+        out = self._g.get(key)
+        if out is None or out.device != t.device:
+            out = self._g[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        out.copy_(t.unsqueeze(0).expand_as(out))
+        self.bytes["all_gather"] += (self.world - 1) * t.numel() * t.element_size()
+        return out, _Done()
+
+    def all_to_all(self, t, async_op=False, out=None):
+        self.bytes["all_to_all"] += (self.world - 1) * (t.numel() // self.world) * t.element_size()
+        if out is not None:
+            out.copy_(t)
+            return out, _Done()
+        return t.contiguous(), _Done()
+
+    def shift_from_prev(self, t, async_op=False):
+        self.bytes["shift"] += t.numel() * t.element_size()
+        return t.contiguous(), _Done()
+
+
 class _Works:
     def __init__(self, works, keep=None):
         self.works, self.keep = works, keep            # `keep`: the send buffer must outlive the transfer
