@@ -61,6 +61,15 @@ static_assert(HC_LDS <= 160 * 1024, "LDS");
 #ifndef HC_PROFILE
 #define HC_PROFILE 0
 #endif
+#ifndef HC_SPREAD
+#define HC_SPREAD 1                         // 1: window pieces / stores interleaved with the arithmetic; 0: all of them right behind the barrier
+#endif
+#ifndef HC_PREF
+#define HC_PREF 1                           // 1: the window of tile k + 1 is read into registers while tile k is computed (no read phase behind the barrier)
+#endif
+#ifndef HC_YBLK
+#define HC_YBLK 0                           // > 0 (timing probe): y written as [row block of HC_YBLK rows][group][HC_YBLK][16] -- whole lines per store
+#endif
 #define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
 
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
@@ -249,7 +258,13 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
         // counter sees exactly HC_NST stores per interval
         // (also dropped that way: the stores of the first interval, which has no previous tile)
+#if HC_YBLK
+        const uint32_t R = (uint32_t)(c.b * Ti + t0 + row);                       // row of the [B T] matrix
+        const uint32_t yb = ((R / HC_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HC_YBLK * 32) + (R % HC_YBLK) * 32 + (lane & 1) * 16;
+        const uint32_t off = (v.st && (full || t0 + row < Ti)) ? yb : 0xfffffff0u;
+#else
         const uint32_t off = (v.st && (full || t0 + row < Ti)) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
+#endif
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(val), "v"(off), "s"(ysrd) : "memory");
     };
 
@@ -257,31 +272,61 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     //      places the waits where the values are used: the FIR of v and x1 starts while the x2 rows are still on their way)
     constexpr int NQ = HC_CPW == 4 ? 2 : 1;                  // dwords per read
     uint32_t raw[3][10][NQ];
-    auto read_win = [&](int buf, bool next_row_start) {
+#if HC_PREF
+    uint32_t rawn[3][10][NQ];                                // the window of the NEXT tile, on its way while this tile is computed
+#endif
+    auto read_win = [&](uint32_t (&dst)[3][10][NQ], int buf) {
         const uint32_t wm = win_main + buf * HC_WINB;
         const uint32_t wh = from_halo ? halo_rd + buf * (2 * HC_ROWB) : win_hist0 + buf * HC_WINB;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                if (SO && g == 0) { for (int e = 0; e < NQ; ++e) raw[g][i][e] = 0u; continue; }
+                if (SO && g == 0) { for (int e = 0; e < NQ; ++e) dst[g][i][e] = 0u; continue; }
                 const unsigned char* p = smem + (i < 2 ? wh + i * HC_ROWB : wm + (i - 2) * HC_ROWB) + 32 * g;
-                if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; raw[g][i][0] = v[0]; raw[g][i][NQ - 1] = v[1]; }
-                else raw[g][i][0] = *(const uint32_t*)p;
+                if (HC_CPW == 4) { const hc_u32x2 v = *(const hc_u32x2*)p; dst[g][i][0] = v[0]; dst[g][i][NQ - 1] = v[1]; }
+                else dst[g][i][0] = *(const uint32_t*)p;
             }
-        // rows 510, 511 of this tile are the history of the next one: lane 63 holds them (its rows 8, 9)
-        if (lane == 63 && !next_row_start) {
-            unsigned char* hp = smem + HC_OFF_HALO + (buf ^ 1) * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
+    };
+    // rows 510, 511 of a tile are the history of the next one: lane 63 holds them (its rows 8, 9) and leaves them in halo slot `slot`
+    auto put_history = [&](const uint32_t (&src)[3][10][NQ], int slot) {
+        if (lane == 63) {
+            unsigned char* hp = smem + HC_OFF_HALO + slot * (2 * HC_ROWB) + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (HC_CPW == 4) { hc_u32x2 v = {raw[g][8 + i][0], raw[g][8 + i][NQ - 1]}; *(hc_u32x2*)(hp + i * HC_ROWB + 32 * g) = v; }
-                    else *(uint32_t*)(hp + i * HC_ROWB + 32 * g) = raw[g][8 + i][0];
+                    if (HC_CPW == 4) { hc_u32x2 v = {src[g][8 + i][0], src[g][8 + i][NQ - 1]}; *(hc_u32x2*)(hp + i * HC_ROWB + 32 * g) = v; }
+                    else *(uint32_t*)(hp + i * HC_ROWB + 32 * g) = src[g][8 + i][0];
                 }
         }
     };
+    // FIR history of a new batch row (or zeros) into halo slot `slot` (wave 0)
+    auto seed_history = [&](int b, int slot) {
+        if (wave == 0 && lane < 48) {
+            const int r = lane / 24, wq = lane - 24 * r;     // 24 dwords per row: x2 | x1 | v
+            uint32_t v = 0u;
+            if (a.z_halo) {
+                const uint32_t* hp = a.z_halo + ((int64_t)b * 2 + r) * (a.D * 6 / 4) + cg * (HC_ROWB / 4) + wq;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(hp) : "memory");
+            }
+            *(uint32_t*)(smem + HC_OFF_HALO + slot * (2 * HC_ROWB) + r * HC_ROWB + wq * 4) = v;
+        }
+    };
 
+#if HC_SPREAD == 1
+#define HC_VMP(I) vm_piece(vm, (I))
+#define HC_VMS(I) vm_store(vm, (I))
+#define HC_VMF(I)
+#elif HC_SPREAD == 2      // the pieces inside the FIR loops (the first ~40 % of the tile's arithmetic: they land before the next barrier)
+#define HC_VMP(I)
+#define HC_VMS(I) vm_store(vm, (I))
+#define HC_VMF(I) { if ((I) < HC_PPW) vm_piece(vm, (I)); }
+#else
+#define HC_VMP(I)
+#define HC_VMS(I)
+#define HC_VMF(I)
+#endif
     // ---- one tile of this wave's channels, from the registers read_win filled
     auto compute = [&](const Cur& c, int buf, const Vm& vm, auto ragged_t) {
         constexpr bool RAGGED = decltype(ragged_t)::value;
@@ -301,7 +346,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         }
         const int n_valid = RAGGED ? Ti - (t0 + 32 * la + 8 * lq) : 8;         // steps of this lane inside the sequence
         static_assert(HC_PPW == 1 + 2 * HC_NPAIR + 2 * HC_CPW && HC_NST == HC_CPW, "issue points of the window pieces / stores");
-        vm_piece(vm, 0);
+        HC_VMP(0);
 
         bf16x8_t xh[HC_CPW];
 #if HC_XLO
@@ -325,9 +370,10 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     x[i] = x1c * vc;
                     if (RAGGED && i >= n_valid) { x[i][0] = 0.f; x[i][1] = 0.f; }      // past the end: nothing enters the modes
                     m2a = m1a; m1a = ca; m2b = m1b; m1b = cb;
+                    if ((i & 1) == 0) HC_VMF(7 * pp + (i >> 1));
                 }
             }
-            vm_piece(vm, 1 + 2 * pp);
+            HC_VMP(1 + 2 * pp);
             if (!SO) {
                 const f32x2_t* fp_ = fwl + pp * 12;
                 const f32x2_t w00 = fp_[0], w01 = fp_[1], w02 = fp_[2], b0f = fp_[3];
@@ -337,9 +383,10 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     const f32x2_t cx = hc_bf2(raw[0][i + 2][pp]);
                     x2f[pp][i] = hc_fma(w02, cx, hc_fma(w01, m1, hc_fma(w00, m2, b0f)));
                     m2 = m1; m1 = cx;
+                    if (i % 3 == 0) HC_VMF(7 * pp + 4 + i / 3);
                 }
             }
-            vm_piece(vm, 2 + 2 * pp);
+            HC_VMP(2 + 2 * pp);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 uint32_t hw[4];
@@ -382,7 +429,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                     yv[cc][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(8 * mt), xh[cc], acc, 0, 0, 0);
                 }
             HC_FENCE_NOP();
-            vm_piece(vm, 1 + 2 * HC_NPAIR + 2 * cc);
+            HC_VMP(1 + 2 * HC_NPAIR + 2 * cc);
             // Kogge-Stone scan of the 16 block aggregates -> state entering every block; the tile's end state
             float sv[4] = {e[0], e[1], e[2], e[3]};
             const hc_f32x4* pwc = (const hc_f32x4*)(pwl + (ch0 + cc) * 64) + lq;
@@ -429,7 +476,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[r]), 0x121, 0xf, 0xf, false));
-            vm_piece(vm, 2 + 2 * HC_NPAIR + 2 * cc);
+            HC_VMP(2 + 2 * HC_NPAIR + 2 * cc);
             if (WS && last_tile) {
                 // state after the last token T - 1, which sits in block a_ at local step r_ - 1: the recurrence over the block's first
                 // r_ steps from the state entering it.  Lane s (< 8) takes mode s.  The x values are the very bf16 terms the matrix
@@ -486,7 +533,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 }
                 HC_FENCE_NOP();
             }
-            vm_store(vm, cc);                                // (tile k - 1, staged before the barrier; one 16-byte store per lane)
+            HC_VMS(cc);                                      // (tile k - 1, staged before the barrier; one 16-byte store per lane)
 #undef HC_FRAG
         }
         // ---- gate and stage: accumulator (mt, r) of a lane is its step 4 mt + r; one dword (two channels) per step and pair
@@ -516,6 +563,78 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #define HC_STAMP(K)
 #endif
     Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
+#if HC_PREF
+    // ---- prefetching form: behind barrier k a wave reads the window of tile k + 1 (landed: its pieces were issued during interval
+    //      k - 1) into a second register set and THEN computes tile k from the set it read an interval ago -- the 30 LDS reads per
+    //      wave (a 1.5 k-clock phase when all eight waves wait for them behind the barrier) fly under the arithmetic.  Buffer k & 1
+    //      (window k: in registers everywhere, every wave passes the barrier with lgkmcnt(0)) takes the pieces of tile k + 2.
+    if (n_steps > 0) {
+        dma_win(c_dma, 0); advance(c_dma);
+        if (c_cmp.tile == 0) seed_history(c_cmp.b, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_win(raw, 0);
+        if (n_steps > 1) { dma_win(c_dma, 1); advance(c_dma); }
+        Cur n1 = c_cmp;
+        advance(n1);
+        if (n_steps > 1 && n1.tile != 0) put_history(raw, 1);
+    }
+#if HC_PROFILE
+    tlast = __builtin_readcyclecounter();
+#endif
+    for (int k = 0; k <= n_steps; ++k) {
+        const int buf = k & 1;
+        Cur nx = c_cmp;
+        advance(nx);
+        Cur nx2 = nx;
+        advance(nx2);
+        if (k + 1 < n_steps && nx.tile == 0) seed_history(nx.b, buf ^ 1);       // tile k + 1 starts a batch row
+        // interval k - 1 issued, in this order: ..., the last piece of window(k + 1), ONE more store (the prologue: no store)
+        if (!SO && k >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HC_SPREAD == 1 ? 1 : HC_NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HC_STAMP(0);
+        __syncthreads();                                     // window(k + 1) and its history slot -> everybody; staging(k - 1) complete
+        HC_STAMP(1);
+        if (k + 1 < n_steps) read_win(rawn, buf ^ 1);
+        HC_STAMP(5);
+        Vm vm;
+        vm.dma = k + 2 < n_steps;
+        vm_prepare(vm, c_dma, buf);
+        if (vm.dma) advance(c_dma);
+        vm.st = !SO && k >= 1;
+        vm.cst = c_st;
+        vm.sbuf = buf ^ 1;
+        if (vm.st) advance(c_st);
+#if HC_SPREAD == 0
+#pragma unroll
+        for (int i = 0; i < HC_PPW; ++i) vm_piece(vm, i);
+        HC_STAMP(2);
+        if (k < n_steps) {
+#pragma unroll
+            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);
+        }
+        HC_STAMP(3);
+#endif
+        if (k < n_steps) {
+            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, vm, hc_false{});
+            else compute(c_cmp, buf, vm, hc_true{});
+            c_cmp = nx;
+            if (k + 1 < n_steps) {
+                if (k + 2 < n_steps && nx2.tile != 0) put_history(rawn, buf);    // rows 510, 511 of tile k + 1 -> history of tile k + 2
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < 10; ++i)
+#pragma unroll
+                        for (int e = 0; e < NQ; ++e) raw[g][i][e] = rawn[g][i][e];
+            }
+        } else {
+#pragma unroll
+            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);      // the last tile's outputs
+        }
+        HC_STAMP(4);
+    }
+#else
     if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
 #if HC_PROFILE
     tlast = __builtin_readcyclecounter();
@@ -526,17 +645,9 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         advance(nx);
         const bool next_row_start = nx.tile == 0;
         if (k < n_steps) {
-            if (c_cmp.tile == 0 && wave == 0 && lane < 48) {  // a new row: its FIR history (or zeros) into this tile's halo slot
-                const int r = lane / 24, wq = lane - 24 * r; // 24 dwords per row: x2 | x1 | v
-                uint32_t v = 0u;
-                if (a.z_halo) {
-                    const uint32_t* hp = a.z_halo + ((int64_t)c_cmp.b * 2 + r) * (a.D * 6 / 4) + cg * (HC_ROWB / 4) + wq;
-                    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(hp) : "memory");
-                }
-                *(uint32_t*)(smem + HC_OFF_HALO + buf * (2 * HC_ROWB) + r * HC_ROWB + wq * 4) = v;
-            }
+            if (c_cmp.tile == 0) seed_history(c_cmp.b, buf);  // a new row: its FIR history (or zeros) into this tile's halo slot
             // interval k - 1 issued, in this order: ..., the last piece of window(k), ONE more store (of tile k - 2; dropped when k = 1)
-            if (!SO && k >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (!SO && k >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HC_SPREAD == 1 ? 1 : HC_NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         HC_STAMP(0);
@@ -550,8 +661,19 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         vm.cst = c_st;
         vm.sbuf = buf ^ 1;
         if (vm.st) advance(c_st);
+#if HC_SPREAD == 0
+#pragma unroll
+        for (int i = 0; i < HC_PPW; ++i) vm_piece(vm, i);
+        HC_STAMP(2);
         if (k < n_steps) {
-            read_win(buf, next_row_start);
+#pragma unroll
+            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);
+        }
+        HC_STAMP(3);
+#endif
+        if (k < n_steps) {
+            read_win(raw, buf);
+            if (!next_row_start) put_history(raw, buf ^ 1);
             HC_STAMP(5);
             if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, vm, hc_false{});
             else compute(c_cmp, buf, vm, hc_true{});
@@ -562,6 +684,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         }
         HC_STAMP(4);
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if HC_PROFILE
     if (lane == 0) {
