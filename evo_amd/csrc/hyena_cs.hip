@@ -64,9 +64,6 @@ static_assert(HC_LDS <= 160 * 1024, "LDS");
 #ifndef HC_SPREAD
 #define HC_SPREAD 1                         // 1: window pieces / stores interleaved with the arithmetic; 0: all of them right behind the barrier
 #endif
-#ifndef HC_PREF
-#define HC_PREF 1                           // 1: the window of tile k + 1 is read into registers while tile k is computed (no read phase behind the barrier)
-#endif
 #ifndef HC_YBLK
 #define HC_YBLK 0                           // > 0 (timing probe): y written as [row block of HC_YBLK rows][group][HC_YBLK][16] -- whole lines per store
 #endif
@@ -202,7 +199,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     // (tools/hc_stage_profile.py, round 4: per tile 8.4 k clocks = 2.9 k DMA issue + 0.6 k stores + 1.1 k window reads + 3.5 k
     // compute, one after the other).  `vm_prepare` builds the tile's descriptor, `vm_piece` issues ONE piece; `compute` calls it
     // at points spread over the tile's arithmetic, so that a wave's memory instructions queue while its partner on the SIMD computes.
-    struct Vm { hc_srd d; uint32_t base; bool dma; bool st; Cur cst; int sbuf; };
+    struct Vm { hc_srd d; uint32_t base; bool dma; bool st; Cur cst; int sbuf; hc_u32x4 sdat[HC_NST]; };
     auto vm_prepare = [&](Vm& v, const Cur& c, int buf) {
         // descriptor of this tile of the (group, batch row) stream: base = first row of the tile, num_records = bytes up to the
         // end of the row's T tokens (the hardware returns zeros beyond: the ragged last tile needs no clamping)
@@ -247,6 +244,16 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     const float first_blk = la == 0 ? 1.f : 0.f;
 
     // ---- store of tile `c` from staging buffer `buf`: the wave's HC_RW rows x 32 B, 16 B per lane
+    // the staged outputs of tile k - 1 go to registers right behind the barrier (with the window reads: one LDS round trip for both);
+    // the stores themselves are issued later, between the arithmetic
+    auto vm_store_fetch = [&](Vm& v) {
+        if (SO) return;
+#pragma unroll
+        for (int hs = 0; hs < HC_NST; ++hs) {
+            const int row = HC_RW * wave + 32 * hs + (lane >> 1);
+            v.sdat[hs] = *(const hc_u32x4*)(smem + HC_OFF_STG + v.sbuf * HC_STGB + row * 32 + (row >> 5) * 16 + (lane & 1) * 16);
+        }
+    };
     auto vm_store = [&](const Vm& v, const int hs) {
         if (SO) return;
         const Cur& c = v.cst;
@@ -254,10 +261,9 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         const bool full = t0 + HC_TT <= Ti;
         const uint32_t row0 = (uint32_t)(((int64_t)c.b * Ti + t0) * a.y_rowbytes + d0 * 2);
         const int row = HC_RW * wave + 32 * hs + (lane >> 1);
-        const hc_u32x4 val = *(const hc_u32x4*)(smem + HC_OFF_STG + v.sbuf * HC_STGB + row * 32 + (row >> 5) * 16 + (lane & 1) * 16);
         // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
-        // counter sees exactly HC_NST stores per interval
-        // (also dropped that way: the stores of the first interval, which has no previous tile)
+        // counter sees exactly HC_NST stores per interval (also dropped that way: the stores of the first interval, which has
+        // no previous tile)
 #if HC_YBLK
         const uint32_t R = (uint32_t)(c.b * Ti + t0 + row);                       // row of the [B T] matrix
         const uint32_t yb = ((R / HC_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HC_YBLK * 32) + (R % HC_YBLK) * 32 + (lane & 1) * 16;
@@ -265,16 +271,13 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #else
         const uint32_t off = (v.st && (full || t0 + row < Ti)) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
 #endif
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(val), "v"(off), "s"(ysrd) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v.sdat[hs]), "v"(off), "s"(ysrd) : "memory");
     };
 
     // ---- the window of a tile into registers: ten rows (two of history) x three signals, 8 bytes = 4 channels each (the compiler
     //      places the waits where the values are used: the FIR of v and x1 starts while the x2 rows are still on their way)
     constexpr int NQ = HC_CPW == 4 ? 2 : 1;                  // dwords per read
     uint32_t raw[3][10][NQ];
-#if HC_PREF
-    uint32_t rawn[3][10][NQ];                                // the window of the NEXT tile, on its way while this tile is computed
-#endif
     auto read_win = [&](uint32_t (&dst)[3][10][NQ], int buf) {
         const uint32_t wm = win_main + buf * HC_WINB;
         const uint32_t wh = from_halo ? halo_rd + buf * (2 * HC_ROWB) : win_hist0 + buf * HC_WINB;
@@ -412,6 +415,11 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #pragma unroll
         for (int cc = 0; cc < HC_CPW; ++cc) {
             const uint32_t* t_ = tb[cc];
+            // the four scan powers of the channel, requested HERE: the scan's levels are asm blocks the compiler keeps in order, and a
+            // load placed next to its level waits out the whole LDS latency four times per channel (round 4: ~2 k clocks per tile)
+            const hc_f32x4* pwc = (const hc_f32x4*)(pwl + (ch0 + cc) * 64) + lq;
+            const hc_f32x4 pw4[4] = {pwc[0], pwc[4], pwc[8], pwc[12]};
+            __builtin_amdgcn_sched_barrier(0);               // (the loads stay in front of the MFMA burst: its ~250 clocks cover their latency)
 #define HC_FRAG(BASE) __builtin_bit_cast(bf16x8_t, hc_u4(t_[(BASE)], t_[(BASE) + 1], t_[(BASE) + 2], t_[(BASE) + 3]))
             const hc_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             hc_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HC_FRAG(20), xh[cc], zero4, 0, 0, 0);       // W_mid . X_hi
@@ -432,9 +440,8 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
             HC_VMP(1 + 2 * HC_NPAIR + 2 * cc);
             // Kogge-Stone scan of the 16 block aggregates -> state entering every block; the tile's end state
             float sv[4] = {e[0], e[1], e[2], e[3]};
-            const hc_f32x4* pwc = (const hc_f32x4*)(pwl + (ch0 + cc) * 64) + lq;
             {
-                const hc_f32x4 P = pwc[0];
+                const hc_f32x4 P = pw4[0];
                 const float c0 = first_blk * carry[cc][0], c1 = first_blk * carry[cc][1], c2 = first_blk * carry[cc][2], c3 = first_blk * carry[cc][3];
                 sv[0] = fmaf(-P[1], c1, fmaf(P[0], c0, sv[0]));
                 sv[1] = fmaf(P[1], c0, fmaf(P[0], c1, sv[1]));
@@ -450,7 +457,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
             // instructions around the block.
 #define HC_LEVEL(KK, SH, PRE, POST)                                                                                       \
             {                                                                                                             \
-                const hc_f32x4 P = pwc[4 * (KK)];                                                                         \
+                const hc_f32x4 P = pw4[(KK)];                                                                             \
                 float t1, t3;                                                                                             \
                 asm volatile(PRE                                                                                          \
                              "v_mov_b32 %2, %4\n\t"                                                                       \
@@ -563,78 +570,6 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #define HC_STAMP(K)
 #endif
     Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
-#if HC_PREF
-    // ---- prefetching form: behind barrier k a wave reads the window of tile k + 1 (landed: its pieces were issued during interval
-    //      k - 1) into a second register set and THEN computes tile k from the set it read an interval ago -- the 30 LDS reads per
-    //      wave (a 1.5 k-clock phase when all eight waves wait for them behind the barrier) fly under the arithmetic.  Buffer k & 1
-    //      (window k: in registers everywhere, every wave passes the barrier with lgkmcnt(0)) takes the pieces of tile k + 2.
-    if (n_steps > 0) {
-        dma_win(c_dma, 0); advance(c_dma);
-        if (c_cmp.tile == 0) seed_history(c_cmp.b, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        read_win(raw, 0);
-        if (n_steps > 1) { dma_win(c_dma, 1); advance(c_dma); }
-        Cur n1 = c_cmp;
-        advance(n1);
-        if (n_steps > 1 && n1.tile != 0) put_history(raw, 1);
-    }
-#if HC_PROFILE
-    tlast = __builtin_readcyclecounter();
-#endif
-    for (int k = 0; k <= n_steps; ++k) {
-        const int buf = k & 1;
-        Cur nx = c_cmp;
-        advance(nx);
-        Cur nx2 = nx;
-        advance(nx2);
-        if (k + 1 < n_steps && nx.tile == 0) seed_history(nx.b, buf ^ 1);       // tile k + 1 starts a batch row
-        // interval k - 1 issued, in this order: ..., the last piece of window(k + 1), ONE more store (the prologue: no store)
-        if (!SO && k >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HC_SPREAD == 1 ? 1 : HC_NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        HC_STAMP(0);
-        __syncthreads();                                     // window(k + 1) and its history slot -> everybody; staging(k - 1) complete
-        HC_STAMP(1);
-        if (k + 1 < n_steps) read_win(rawn, buf ^ 1);
-        HC_STAMP(5);
-        Vm vm;
-        vm.dma = k + 2 < n_steps;
-        vm_prepare(vm, c_dma, buf);
-        if (vm.dma) advance(c_dma);
-        vm.st = !SO && k >= 1;
-        vm.cst = c_st;
-        vm.sbuf = buf ^ 1;
-        if (vm.st) advance(c_st);
-#if HC_SPREAD == 0
-#pragma unroll
-        for (int i = 0; i < HC_PPW; ++i) vm_piece(vm, i);
-        HC_STAMP(2);
-        if (k < n_steps) {
-#pragma unroll
-            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);
-        }
-        HC_STAMP(3);
-#endif
-        if (k < n_steps) {
-            if (c_cmp.tile * HC_TT + HC_TT <= Ti) compute(c_cmp, buf, vm, hc_false{});
-            else compute(c_cmp, buf, vm, hc_true{});
-            c_cmp = nx;
-            if (k + 1 < n_steps) {
-                if (k + 2 < n_steps && nx2.tile != 0) put_history(rawn, buf);    // rows 510, 511 of tile k + 1 -> history of tile k + 2
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int i = 0; i < 10; ++i)
-#pragma unroll
-                        for (int e = 0; e < NQ; ++e) raw[g][i][e] = rawn[g][i][e];
-            }
-        } else {
-#pragma unroll
-            for (int hs = 0; hs < HC_NST; ++hs) vm_store(vm, hs);      // the last tile's outputs
-        }
-        HC_STAMP(4);
-    }
-#else
     if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
 #if HC_PROFILE
     tlast = __builtin_readcyclecounter();
@@ -661,6 +596,7 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         vm.cst = c_st;
         vm.sbuf = buf ^ 1;
         if (vm.st) advance(c_st);
+        vm_store_fetch(vm);
 #if HC_SPREAD == 0
 #pragma unroll
         for (int i = 0; i < HC_PPW; ++i) vm_piece(vm, i);
@@ -684,7 +620,6 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         }
         HC_STAMP(4);
     }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if HC_PROFILE
     if (lane == 0) {
