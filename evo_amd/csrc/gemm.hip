@@ -348,8 +348,13 @@ static_assert(!GE_FULL || GE_ORDER == 1, "GE_FULL pairs the strips of GE_ORDER 1
 #define GR_PROFILE 0                         // 1: wave 0 of workgroup 0 accumulates cycles per loop segment, written over y (tools/gemm_stage_profile.py)
 #endif
 
-template <bool BIAS, bool RES, int MODE>            // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; 2: group-major z for the Hyena operator
+// XB (round 4): the X operand is the BLOCKED output of the channel-stationary Hyena operator (csrc/hyena_cs.hip),
+//   [row block of 128][K / 16 groups][128 rows][16 channels] bf16 -- a 64-channel slab of a row is four 32-byte pieces 4 KiB apart
+//   instead of one 128-byte piece; only the DMA's SOURCE addresses change (the lane that fills granule s of LDS row r fetches
+//   32-byte piece s >> 1, half s & 1), the k-step is 16 KiB instead of 128 B; the tile origin m0 * K * 2 is the same number.
+template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; 2: group-major z for the Hyena operator
 __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
+    constexpr uint32_t XSTEP = XB ? 16384u : (uint32_t)(GBK * 2);   // bytes from one k-step's X slab to the next
     __shared__ __attribute__((aligned(16))) unsigned char smem[G_NSLOT * G_SLAB];   // the ONLY __shared__ object
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -387,7 +392,9 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     //      slot s of row r fetches granule s ^ (r & 7) of that row (a fragment read touches 16 consecutive rows x 4 granules:
     //      8 consecutive rows hit 8 different slots = all 32 banks).  Rows of one lane are 32 apart: same swizzle term.
     const int r0 = 8 * wave + (lane >> 3);
-    const uint32_t voff0 = (uint32_t)r0 * kb + (uint32_t)((((lane & 7) ^ r0) & 7) * 16);
+    const uint32_t xs_ = (uint32_t)(((lane & 7) ^ r0) & 7);       // source granule of this lane's LDS slot
+    const uint32_t voff0 = XB ? (uint32_t)r0 * 32u + (xs_ >> 1) * 4096u + (xs_ & 1) * 16u
+                              : (uint32_t)r0 * kb + xs_ * 16;
     const uint32_t row32 = 32u * kb;                             // voffset of piece jj = voff0 + jj * row32
     uint32_t voff[8], wvoff[8];
     // W slabs: LDS row 32 b + 16 t + 4 q + r holds W row 32 b + 8 q + 4 t + r (a relabelling inside 32-row blocks: every row is
@@ -395,9 +402,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     const int wrow = 8 * ((r0 >> 2) & 3) + 4 * ((r0 >> 4) & 1) + (r0 & 3);
     const uint32_t wvoff0 = (uint32_t)wrow * kb + (uint32_t)((((lane & 7) ^ r0) & 7) * 16);
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) { voff[jj] = voff0 + jj * row32; wvoff[jj] = wvoff0 + jj * row32; }
+    for (int jj = 0; jj < 8; ++jj) {
+        // (blocked X: rows r0 + 32 jj of the 256-row tile = row (r0 + 32 jj) & 127 of row block jj >> 2, 128 * kb bytes apart)
+        voff[jj] = XB ? voff0 + (uint32_t)(jj & 3) * 1024u + (uint32_t)(jj >> 2) * 128u * kb : voff0 + jj * row32;
+        wvoff[jj] = wvoff0 + jj * row32;
+    }
     const uint64_t xa64 = (uint64_t)a.x, wa64 = (uint64_t)a.w;
-    const g_u32x4 rx = {(uint32_t)xa64, (uint32_t)(xa64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.M * kb), 0x00020000u};
+    const g_u32x4 rx = {(uint32_t)xa64, (uint32_t)(xa64 >> 32) & 0xffffu,
+                        (uint32_t)((XB ? (a.M + 127) / 128 * 128 : a.M) * (int64_t)kb), 0x00020000u};
     const g_u32x4 rw = {(uint32_t)wa64, (uint32_t)(wa64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.N * kb), 0x00020000u};
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t lds_dma = lds0 + wave * 1024;                 // + slot * G_SLAB + jj * 4096
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
         fws = (uint32_t)n0 * kb;
     }
     auto fetch_advance = [&]() {                                 // (prologue only; past the last stage: stay)
-        if (f_k + 1 < nk) { ++f_k; fxs += GBK * 2; fws += GBK * 2; }
+        if (f_k + 1 < nk) { ++f_k; fxs += XSTEP; fws += GBK * 2; }
         else if (f_i + 1 < n_my) {
             ++f_i; f_k = 0;
             int64_t m0; int n0;
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
         if constexpr (g_ >= 64 && s_ < 8 * GR_DGAP && (s_ % GR_DGAP) == GR_DGAP / 2 + 1 && !(GR_ABL & 1)) GD_DMAW(s_ / GR_DGAP);      \
         /* scalar bookkeeping of the NEXT k-step, <= 3 instructions per gap, in gaps that carry no memory instruction and no   */ \
         /* M0 write (half 1: this k-step's X pieces are out; the W pieces end at gap 125; slot offsets are dead once read).    */ \
-        if constexpr (g_ == 67) { fxp = fxs + GBK * 2; fwp = fws + GBK * 2; GS_PIN2(fxp, fwp); }              \
+        if constexpr (g_ == 67) { fxp = fxs + XSTEP; fwp = fws + GBK * 2; GS_PIN2(fxp, fwp); }              \
         if constexpr (g_ == 71) { f_rem -= 1; GS_PIN1(f_rem); }                                               \
         if constexpr (g_ == 75) { nfxs = f_rem == 0 ? nx0 : fxp; GS_PIN1(nfxs); }                             \
         if constexpr (g_ == 87) { nfws = f_rem == 0 ? nw0 : fwp; GS_PIN1(nfws); }                             \
@@ -852,6 +864,35 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
     else if (bias) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, a);
     else if (residual) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, a);
+    return evo_launch_status();
+}
+
+// y [M, N] = x . w^T + residual with x in the BLOCKED layout the channel-stationary Hyena operator writes
+// ([ceil(M / 128)][K / 16][128][16] bf16): the Hyena block's output projection [REF stripedhyena/model.py ParallelGatedConvBlock.forward:
+// out_filter_dense].  M % 256 == 0 (the caller peels the BOS sliver), K % 64 == 0, K >= 128.
+extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* residual, void* y,
+                                         int64_t M, int64_t N, int64_t K, void* stream) {
+    if (M <= 0 || M % GBM != 0 || N <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || K < 2 * GBK || N > 0x7fffffff / 2) return -1;
+    if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
+    GemmArgs a;
+    a.x = (const unsigned char*)x_blk; a.w = (const unsigned char*)w; a.bias = nullptr;
+    a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
+    a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = M;
+    a.tiles_n = (int)(N / GBN);
+    a.tiles_m = (int)(M / GBM);
+    a.group_m = a.tiles_n >= 32 ? 8 : 4;
+    const int64_t tiles = (M / GBM) * a.tiles_n;
+    if (tiles > 0x7fffffff) return -1;
+    a.n_tiles = (int)tiles;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        n &= ~7;
+        return n < 8 ? 8 : n;
+    }();
+    const dim3 gridp((unsigned)n_cu), block4(256);
+    if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }
 

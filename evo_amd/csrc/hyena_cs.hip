@@ -62,11 +62,10 @@ static_assert(HC_LDS <= 160 * 1024, "LDS");
 #define HC_PROFILE 0
 #endif
 #ifndef HC_SPREAD
-#define HC_SPREAD 1                         // 1: window pieces / stores interleaved with the arithmetic; 0: all of them right behind the barrier
+#define HC_SPREAD 0                         // 0: the window pieces / stores right behind the barrier (default: measured best with the blocked y);
+                                            // 1: interleaved with the whole tile's arithmetic; 2: the pieces inside the FIR loops
 #endif
-#ifndef HC_YBLK
-#define HC_YBLK 0                           // > 0 (timing probe): y written as [row block of HC_YBLK rows][group][HC_YBLK][16] -- whole lines per store
-#endif
+#define HC_YBLK 128                         // rows per block of the BLOCKED y layout (HcArgs.y_blk): [row block][group][128 rows][16 channels]
 #define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
 
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
@@ -84,7 +83,13 @@ __device__ __forceinline__ float hc_shr(float v) {          // value of lane (a 
 
 // With two waves per SIMD sharing the matrix pipe hipcc under-pads MFMA -> consumer distances (hyena_mfma.hip, round 2): the
 // bursts are fenced there.  One wave per SIMD (HC_NW = 4) is the case its hazard recogniser models: no fences.
-#if HC_NW == 8
+#ifndef HC_NOFENCE
+#define HC_NOFENCE 0
+#endif
+#ifndef HC_PRIO
+#define HC_PRIO 0                           // 1: the second half of the waves (the losers of the age-based issue arbitration) run at priority 1
+#endif
+#if HC_NW == 8 && !HC_NOFENCE
 #define HC_FENCE_NOP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define HC_FENCE_NOP() do { } while (0)
@@ -99,6 +104,8 @@ struct HcArgs {
     int B; int T; int D; int n_tiles; int n_groups; int nb_split;
     int64_t z_group_rows;                                   // rows between two groups' streams in z (>= B * T)
     int64_t y_rowbytes;
+    int y_blk;                                              // y is [ceil(rows / 128)][D / 16][128][16] bf16 instead of [rows][D] (see vm_store)
+    int64_t y_row0, y_rows;                                 // blocked y: row of batch row 0 / total rows of the [rows, D] matrix it stands for
 };
 
 // words of a channel's table kept in registers: T0 [mt 2][hi, lo][4] = 0..15, W [hi, mid][4] = 16..23, G [mt 2][4] = 24..31
@@ -237,7 +244,8 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
     const bool from_halo = lane == 0;
     const uint32_t stg_wr = HC_OFF_STG + (32 * la + 8 * lq) * 32 + la * 16 + q4 * 8 + (HC_CPW == 2 ? 4 * HALF : 0);
     const uint64_t y64 = (uint64_t)a.y;
-    const hc_u32x4 ysrd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.B * Ti * a.y_rowbytes), 0x00020000u};
+    const hc_u32x4 ysrd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu,
+                           (uint32_t)((a.y_blk ? (a.y_rows + HC_YBLK - 1) / HC_YBLK * HC_YBLK : (int64_t)a.B * Ti) * a.y_rowbytes), 0x00020000u};
     const uint32_t yrb = (uint32_t)a.y_rowbytes;
 
     float carry[HC_CPW][4];                                  // tile-entering state: components 4 lq .. 4 lq + 3, valid in lanes la = 0
@@ -264,13 +272,13 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
         // bounds-checked buffer store: rows past the end get an offset beyond num_records and are dropped, so that the VM
         // counter sees exactly HC_NST stores per interval (also dropped that way: the stores of the first interval, which has
         // no previous tile)
-#if HC_YBLK
-        const uint32_t R = (uint32_t)(c.b * Ti + t0 + row);                       // row of the [B T] matrix
+        // Row-major y costs a store instruction ~270 clocks at the vector-memory unit (its 32 rows are 32 different cache lines,
+        // 32 B of each) -- 16 stores per tile and CU were ~4 k of the ~8.4 k clocks a tile took.  The BLOCKED form keeps a group's
+        // 16 channels of 128 consecutive rows together (4 KiB): a store instruction covers 8 whole lines, +13...21 % on the kernel
+        // (profiles/r04_hyena_cs_notes.txt); the output projection's dense layer gathers it (csrc/gemm.hip, XB).
+        const uint32_t R = (uint32_t)(a.y_row0 + (int64_t)c.b * Ti + t0 + row);  // row of the [rows, D] matrix
         const uint32_t yb = ((R / HC_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HC_YBLK * 32) + (R % HC_YBLK) * 32 + (lane & 1) * 16;
-        const uint32_t off = (v.st && (full || t0 + row < Ti)) ? yb : 0xfffffff0u;
-#else
-        const uint32_t off = (v.st && (full || t0 + row < Ti)) ? row0 + (uint32_t)row * yrb + (lane & 1) * 16 : 0xfffffff0u;
-#endif
+        const uint32_t off = !(v.st && (full || t0 + row < Ti)) ? 0xfffffff0u : (a.y_blk ? yb : row0 + (uint32_t)row * yrb + (lane & 1) * 16);
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v.sdat[hs]), "v"(off), "s"(ysrd) : "memory");
     };
 
@@ -570,6 +578,9 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
 #define HC_STAMP(K)
 #endif
     Cur c_cmp = {b0, 0}, c_dma = {b0, 0}, c_st = {b0, 0};
+#if HC_PRIO
+    if (wave >= HC_NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if (n_steps > 0) { dma_win(c_dma, 0); advance(c_dma); }
 #if HC_PROFILE
     tlast = __builtin_readcyclecounter();
@@ -647,10 +658,11 @@ __global__ __launch_bounds__(HC_THREADS, 1) void hyena_cs_kernel(HcArgs a) {
 
 extern "C" int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                                const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                               int64_t z_group_rows, int64_t state_only, void* stream) {
+                               int64_t z_group_rows, int64_t state_only, int64_t y_blocked_rows, int64_t y_row0, void* stream) {
     if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0 || D != n_heads * 128) return -1;
     const int64_t yrb = D * 2;
     if (B * T * yrb >= 0xfffffff0ll || T * HC_ROWB >= 0x7fffffffll) return -1;     // 32-bit offsets inside y / one stream of z
+    if (y_blocked_rows && (y_row0 < 0 || y_row0 + B * T > y_blocked_rows || (y_blocked_rows + HC_YBLK) * yrb >= 0xfffffff0ll)) return -1;
     if (z_group_rows < B * T) return -1;
     if (s_out && !poles) return -1;
     if (state_only ? !s_out : !y) return -1;
@@ -665,6 +677,7 @@ extern "C" int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fi
     a.tab = (const uint32_t*)table; a.y = (unsigned char*)y; a.s0 = s0; a.s_out = s_out; a.poles = poles;
     a.B = (int)B; a.T = (int)T; a.D = (int)D; a.n_tiles = (int)((T + HC_TT - 1) / HC_TT); a.n_groups = (int)groups;
     a.nb_split = (int)nb_split; a.z_group_rows = z_group_rows; a.y_rowbytes = yrb;
+    a.y_blk = y_blocked_rows ? 1 : 0; a.y_row0 = y_row0; a.y_rows = y_blocked_rows;
     if (state_only) hipLaunchKernelGGL((hyena_cs_kernel<true, true>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);
     else if (s_out) hipLaunchKernelGGL((hyena_cs_kernel<false, true>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((hyena_cs_kernel<false, false>), dim3((unsigned)streams), dim3(HC_THREADS), 0, (hipStream_t)stream, a);

@@ -38,7 +38,8 @@ _SIGNATURES = {
     "evo_mlp_gate_mfma_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
-    "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 6 + [_PTR], _c.c_int),
+    "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 8 + [_PTR], _c.c_int),
+    "evo_linear_xblk_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -475,7 +476,7 @@ class HipOps:
         if zg_shape is not None and self.hyena_cs_flag:
             with self._t("hyena_mfma"):
                 _check(self.lib.evo_hyena_cs_zg(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(),
-                                                y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, B * T, 0,
+                                                y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, B * T, 0, 0, 0,
                                                 _stream()), "evo_hyena_cs_zg")
         else:
             fn = self.lib.evo_hyena_mfma if zg_shape is None else self.lib.evo_hyena_mfma_zg
@@ -488,14 +489,29 @@ class HipOps:
             return y, torch.view_as_complex(s_fin)
         return y
 
+    YBLK = 128          # rows per block of the blocked y layout (csrc/hyena_cs.hip HC_YBLK)
+
+    def yblk_empty(self, rows: int, D: int, device) -> torch.Tensor:
+        """Uninitialised BLOCKED y for a [rows, D] matrix: [ceil(rows / 128), D / 16, 128, 16] bf16 (hyena_cs writes it, the output
+        projection's dense layer reads it: linear_residual_yblk_)."""
+        return torch.empty((rows + self.YBLK - 1) // self.YBLK, D // 16, self.YBLK, 16, dtype=torch.bfloat16, device=device)
+
+    @staticmethod
+    def yblk_to_rows(y_blk: torch.Tensor, rows: int) -> torch.Tensor:
+        """Blocked y -> the row-major [rows, D] matrix it stands for (a copy; tests, and shapes the blocked dense layer does not take)."""
+        nrb, G, R, c = y_blk.shape
+        return y_blk.permute(0, 2, 1, 3).reshape(nrb * R, G * c)[:rows]
+
     def hyena_cs(self, zg, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
-                 state_only=False, row0=0):
+                 state_only=False, row0=0, y_blk=None, y_row0=0):
         """The channel-stationary single-pass operator (csrc/hyena_cs.hip: evo_hyena_cs_zg) on B batch rows of T tokens of a
         GROUP-MAJOR z [D / 16, rows_total, 48] bf16 (linear_zg's result), the first at row `row0` of every group's plane
         (`row0` = b0 * T selects a sub-range of batch rows of a larger tensor: the row groups of a sequence-parallel shard).
         -> y [B,T,D] bf16 | (y, end state [B,D,8] complex64) with `want_state` | the end state alone with `state_only`
         (stage 1 of a sequence-parallel shard: nothing else is written).  `z_halo` [B,2,3D] (grouped column order), `s0`
-        [B,D,8] complex: FIR history / modal state before the first token."""
+        [B,D,8] complex: FIR history / modal state before the first token.
+        `y_blk` (from yblk_empty): the outputs go THERE, blocked, batch row b / token t as row y_row0 + b T + t -- the form the
+        kernel stores fastest and linear_residual_yblk_ reads; the return value is then y_blk (or (y_blk, state))."""
         self._need(zg, torch.bfloat16, "hyena z (group-major)")
         G, rows_total, w48 = zg.shape
         D = G * 16
@@ -518,15 +534,47 @@ class HipOps:
             self._need(poles, torch.float32, "hyena poles")
             assert tuple(poles.shape) == (D, 8, 2)
             s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=zg.device)
-        y = None if state_only else torch.empty(B, T, D, dtype=torch.bfloat16, device=zg.device)
+        yb_rows = 0
+        if state_only:
+            y = None
+        elif y_blk is not None:
+            self._need(y_blk, torch.bfloat16, "hyena y (blocked)")
+            assert y_blk.dim() == 4 and tuple(y_blk.shape[1:]) == (G, self.YBLK, 16)
+            yb_rows = y_blk.shape[0] * self.YBLK
+            assert 0 <= y_row0 and y_row0 + B * T <= yb_rows
+            y = y_blk
+        else:
+            y = torch.empty(B, T, D, dtype=torch.bfloat16, device=zg.device)
         with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
             _check(self.lib.evo_hyena_cs_zg(zg.data_ptr() + row0 * 96, _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
                                             table.data_ptr(), _ptr(y), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads,
-                                            rows_total, 1 if state_only else 0, _stream()), "evo_hyena_cs_zg")
+                                            rows_total, 1 if state_only else 0, yb_rows, y_row0, _stream()), "evo_hyena_cs_zg")
         if state_only:
             return torch.view_as_complex(s_fin)
-        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + y.numel() * 2}
+        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}
         return (y, torch.view_as_complex(s_fin)) if want_state else y
+
+    def linear_residual_yblk_(self, res: torch.Tensor, y_blk: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """res [M, N] += y @ w^T with y given BLOCKED (hyena_cs's y_blk: [ceil(M / 128), K / 16, 128, 16]) -- the Hyena block's output
+        projection on the hand-written dense layer (csrc/gemm.hip, X operand gathered from the blocked form); the last M % 256
+        rows (the BOS sliver) go row-major through the weight-streaming kernel, as everywhere."""
+        M, N = res.shape
+        K = w.shape[1]
+        assert y_blk.shape[0] * self.YBLK >= M and y_blk.shape[1] * 16 == K and res.is_contiguous()
+        Mf = M // 256 * 256
+        ok = (Mf > 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and Mf * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff
+              and w.dtype == torch.bfloat16 and w.is_contiguous())
+        if not ok:
+            return self.linear_residual_(res, self.yblk_to_rows(y_blk, M).contiguous(), w)
+        with self._t("gemm_mfma"):
+            _check(self.lib.evo_linear_xblk_mfma_bf16(y_blk.data_ptr(), w.data_ptr(), res.data_ptr(), res.data_ptr(), Mf, N, K, _stream()),
+                   "evo_linear_xblk_mfma_bf16")
+        if M > Mf:                                           # (<= 255 rows: rows Mf .. M - 1 of the matrix, gathered row-major)
+            r = M - Mf
+            nb0 = Mf // self.YBLK
+            tail = y_blk[nb0:].permute(0, 2, 1, 3).reshape(-1, K)[:r].contiguous()
+            self.linear_residual_(res[Mf:], tail, w)
+        return res
 
     def hyena_mfma_state(self, z, fir_w, fir_b, table, n_heads, poles, z_halo=None, s0=None) -> torch.Tensor:
         """End state [B,D,8] complex64 of the modal recurrence over z [B,T,3D] (GROUPED layout) -- the walk of

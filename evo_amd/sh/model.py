@@ -285,6 +285,9 @@ class StripedHyena(nn.Module):
     def _mixer_out_(self, blk, x2d, y, w, bias, mfma=False):
         """x += y @ w^T (the mixer's output projection); returns the bias still to be added (folded into the next
         RMSNorm pass for prefill-sized batches, into this launch for decode-sized ones)."""
+        if y.dim() == 4:                                     # the Hyena operator's blocked output (ops.hyena_cs)
+            self.ops.linear_residual_yblk_(x2d, y, w)
+            return bias
         if x2d.shape[0] <= self.DECODE_ROWS:
             self.ops.linear_residual_(x2d, y, w, mfma=mfma, bias=bias)
             return None
@@ -359,7 +362,12 @@ class StripedHyena(nn.Module):
                     # scoring: the projection's dense layer writes z GROUP-MAJOR ([D / 16][B T][48]) and the operator reads one
                     # contiguous stream per workgroup (no cache line shared between workgroups: DESIGN.md section 3)
                     zg = ops.linear_zg(n1, wg, bg)
-                    y = ops.hyena_mfma_prefill(zg, f._fir_w, f.short_filter_bias, f.D, table, H, zg_shape=(B, T)).view(B * T, D)
+                    if hasattr(ops, "hyena_cs") and getattr(ops, "hyena_cs_flag", False):
+                        # round 4: the channel-stationary kernel writes y BLOCKED (whole cache lines per store) and the output
+                        # projection's dense layer gathers it: no row-major y exists on this path
+                        y = ops.hyena_cs(zg, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=ops.yblk_empty(B * T, D, zg.device))
+                    else:
+                        y = ops.hyena_mfma_prefill(zg, f._fir_w, f.short_filter_bias, f.D, table, H, zg_shape=(B, T)).view(B * T, D)
                 else:
                     z3 = ops.linear(n1, wg, bg).view(B, T, 3 * D)
                     y = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H).view(B * T, D)
@@ -376,7 +384,7 @@ class StripedHyena(nn.Module):
                     # scoring, plus the carried state in / the end state out
                     zg = ops.linear_zg(n1, wg, bg)
                     y3, state = ops.hyena_cs(zg, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
-                                             want_state=True, poles=f._poles)
+                                             want_state=True, poles=f._poles, y_blk=ops.yblk_empty(B * T, D, zg.device))
                     tail = ops.zg_rows(zg, B, T, T - K1, K1)
                 else:
                     z3 = (ops.linear(n1, wg, bg) if n1 is not None
@@ -384,7 +392,7 @@ class StripedHyena(nn.Module):
                     y3, state = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H, halo, s0=s0,
                                                        want_state=True, poles=f._poles)
                     tail = z3[:, -K1:, :]
-                y = y3.view(B * T, D)
+                y = y3 if y3.dim() == 4 else y3.view(B * T, D)
                 cache.fir_state_dict[i] = tail[..., inv].transpose(1, 2).contiguous()      # [B, 3D, 2], reference order
                 cache.state_dict[i] = state
         else:

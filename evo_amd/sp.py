@@ -376,7 +376,8 @@ class SequenceParallelScorer:
                 st1[g], e_r = ops.hyena_stage1(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, H, z_halo=hg)
             ends[g], works[g] = self._gather0(torch.view_as_real(e_r.to(torch.complex64)), async_op=True,
                                               name="state_allgather")
-        y = torch.empty(B, Tloc, D, dtype=torch.bfloat16 if zgm else z.dtype, device=z.device) if G > 1 else None
+        y = ops.yblk_empty(B * Tloc, D, z.device) if zgm else \
+            (torch.empty(B, Tloc, D, dtype=z.dtype, device=z.device) if G > 1 else None)
         for g in range(G):
             b0, b1 = bounds[g], bounds[g + 1]
             works[g].wait()
@@ -388,7 +389,9 @@ class SequenceParallelScorer:
                 s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
             hg = halo[b0:b1] if halo is not None else None
             if zgm:
-                yg = ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, s0=s0, row0=b0 * Tloc)
+                ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, s0=s0, row0=b0 * Tloc,
+                             y_blk=y, y_row0=b0 * Tloc)       # (blocked y, all row groups into one tensor)
+                continue
             elif fast:
                 yg = ops.hyena_mfma_prefill(z[b0:b1], f._fir_w, f.short_filter_bias, f.D, table, H, hg, s0=s0)
             else:
@@ -398,7 +401,10 @@ class SequenceParallelScorer:
                 y[b0:b1] = yg
             else:
                 y = yg
-        ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
+        if zgm:
+            ops.linear_residual_yblk_(x2d, y, blk.out_filter_dense.weight)
+        else:
+            ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
         m._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
 
     def _attn_block(self, blk, x2d, B, Tloc, Tl, t0, T):

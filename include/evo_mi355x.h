@@ -31,7 +31,8 @@ extern "C" {
  *   4: evo_hyena_mfma gained the carry-in state `s0`, the end state `s_out` and `poles`; evo_hyena_mfma_state added.
  *   5: evo_mlp_gate_mfma_bf16 (GELU * gate in the dense layer's epilogue), evo_linear_zg_mfma_bf16 (group-major result) and
  *      evo_hyena_mfma_zg (the single-pass operator on group-major z) added.
- *   6: evo_hyena_cs_zg (the single-pass operator with channel-stationary waves: outputs, end state or state-only walk) added. */
+ *   6: evo_hyena_cs_zg (the single-pass operator with channel-stationary waves: outputs, end state or state-only walk; blocked y)
+ *      and evo_linear_xblk_mfma_bf16 (the output projection on that blocked y) added. */
 #define EVO_ABI_VERSION 6
 int evo_abi_version(void);
 
@@ -136,10 +137,20 @@ int evo_hyena_mfma_zg(const void* z, const void* z_halo, const void* fir_w, cons
  * z_halo [B, 2, 3 D] bf16 (grouped column order) or NULL; table = the int32 [D, 52, 64] operand table of evo_amd/hyena_tables.py
  * (filter.D folded into the block-Toeplitz diagonal); y [B, T, D] bf16; s0 / s_out [B, D, 8, 2] f32 or NULL; poles [D, 8, 2] f32
  * (needed with s_out).  state_only != 0: no y (may be NULL), only s_out -- stage 1 of a sequence-parallel shard.
+ * y_blocked_rows != 0: y is written BLOCKED, [ceil(y_blocked_rows / 128)][D / 16][128][16] bf16 -- the [y_blocked_rows, D] matrix
+ * with a group's 16 channels of 128 consecutive rows kept together (whole cache lines per store; evo_linear_xblk_mfma_bf16 reads
+ * it); batch row b, token t is row y_row0 + b T + t of that matrix (y_row0 > 0: the row groups of a sequence-parallel shard write
+ * into one tensor).
  * Same arithmetic as evo_hyena_mfma_zg (results agree to fp32 rounding of the block scan).  D == n_heads * 128. */
 int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                     const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                    int64_t z_group_rows, int64_t state_only, void* stream);
+                    int64_t z_group_rows, int64_t state_only, int64_t y_blocked_rows, int64_t y_row0, void* stream);
+
+/* The Hyena block's output projection on the blocked y of evo_hyena_cs_zg            [REF stripedhyena/model.py ParallelGatedConvBlock:
+ * out_filter_dense]:  y [M, N] = x . w^T (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense
+ * layer of evo_linear_mfma_bf16 with other source addresses for its X tiles; M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128. */
+int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* residual, void* y,
+                              int64_t M, int64_t N, int64_t K, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
  * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]

@@ -228,3 +228,29 @@ def test_linear_zg_is_the_dense_layer_in_group_major_order(M, N, K, bias):
     if r:
         d = (z[:, M - r:].double() - want[:, M - r:].double()).abs()
         assert bool((d <= want[:, M - r:].double().abs() * 2.0 ** -7 + 2e-3).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1024, 4096, 4096), (65536 + 8, 4096, 4096), (768 + 200, 512, 256)])
+def test_output_projection_on_the_blocked_hyena_output_is_the_row_major_dense_layer(M, N, K):
+    """evo_linear_xblk_mfma_bf16 (round 4): the Hyena block's output projection reads y in the BLOCKED layout the channel-stationary
+    operator writes ([ceil(M / 128)][K / 16][128][16]).  Only the source addresses of the X tiles differ from evo_linear_mfma_bf16 --
+    the result, residual included, must be that kernel's bit for bit on the 256-row tiles; the last M % 256 rows go through the
+    weight-streaming kernel (<= 16 rows) or the ordinary dense layer and are checked against fp64."""
+    ops = _ops()
+    DEV = "cuda:0"
+    g = torch.Generator(device=DEV).manual_seed(41)
+    y = torch.randn(M, K, generator=g, device=DEV).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).bfloat16()
+    res = torch.randn(M, N, generator=g, device=DEV).bfloat16()
+    nrb = (M + 127) // 128
+    pad = torch.zeros(nrb * 128, K, dtype=torch.bfloat16, device=DEV)
+    pad[:M] = y
+    y_blk = pad.view(nrb, 128, K // 16, 16).permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(ops.yblk_to_rows(y_blk, M), y)
+    got = ops.linear_residual_yblk_(res.clone(), y_blk, w)
+    Mf = M // 256 * 256
+    want = ops.linear_mfma(y[:Mf].contiguous(), w, None, res[:Mf].clone())
+    assert torch.equal(got[:Mf], want)
+    ref = (y.double() @ w.double().t() + res.double())
+    err = (got.double() - ref).abs()
+    assert (err <= ref.abs() * 2.0 ** -8 + 2e-3 * float(ref.abs().max())).all()

@@ -529,6 +529,12 @@ def test_hyena_cs_matches_oracle_and_the_round3_kernel(ops, B, T, D, H):
         y_new, s_new = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles, **kw)
         y_pln = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, **kw)                     # the scoring instantiation (no end state)
         assert torch.equal(y_pln, y_new), list(kw)
+        # the BLOCKED output ([ceil(B T / 128)][D / 16][128][16]: whole cache lines per store): the same numbers in another place
+        yb = ops.yblk_empty(B * T + 77, D, DEV).fill_(7.0)
+        ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, y_blk=yb, y_row0=77, **kw)
+        rows = ops.yblk_to_rows(yb, B * T + 77)
+        assert torch.equal(rows[77:].view(B, T, D), y_new), list(kw)
+        assert bool((rows[:77] == 7.0).all())                                          # nothing written in front of y_row0
         s_only = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, poles=poles, state_only=True, **kw)
         assert torch.equal(torch.view_as_real(s_only), torch.view_as_real(s_new)), list(kw)
         ry, rst = R.op_hyena(z.cpu(), *prm, H, **{k: (halo if k == "z_halo" else s0).cpu() for k in kw})

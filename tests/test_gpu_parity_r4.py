@@ -241,7 +241,11 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
             row0 = kw.get("row0", 0)
             zt = ops.zg_rows(zg[:, row0:row0 + nb * tl, :], nb, tl, 0, tl).clone()        # token-major [nb, tl, 3 D], grouped column order
             halo = kw.get("z_halo")
-            rec[r].append((zt, None if halo is None else halo.clone(), kw.get("s0"), (out[0] if isinstance(out, tuple) else out).clone()))
+            yo = out[0] if isinstance(out, tuple) else out
+            if yo.dim() == 4:                                 # blocked y (all row groups of the shard in one tensor): this launch's rows
+                y0 = kw.get("y_row0", 0)
+                yo = ops.yblk_to_rows(yo, y0 + nb * tl)[y0:]
+            rec[r].append((zt, None if halo is None else halo.clone(), kw.get("s0"), yo.clone()))
         return out
 
     outs, errs = [None] * world, []

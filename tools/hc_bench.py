@@ -2,8 +2,8 @@
 """A/B timing of single-pass Hyena kernels on GROUP-MAJOR z (HIP events on the launch stream), D = 4096, H = 32, at the two bench
 shapes (8 x 8,193 and 1 x 131,073 tokens).
     python tools/hc_bench.py libevo_mi355x.so old:libevo_mi355x.so libevo_hc_nw4.so
-Each argument is a file in evo_amd/_lib/: plain = its evo_hyena_cs_zg (csrc/hyena_cs.hip, round 4), prefix `old:` = its
-evo_hyena_mfma_zg (csrc/hyena_mfma.hip, round 3).  Every build is checked against the three-launch modal operator of the default
+Each argument is a file in evo_amd/_lib/: plain = its evo_hyena_cs_zg (csrc/hyena_cs.hip, round 4) with the BLOCKED y output (what the
+model runs), prefix `rm:` = the same with row-major y, prefix `old:` = its evo_hyena_mfma_zg (csrc/hyena_mfma.hip, round 3).  Every build is checked against the three-launch modal operator of the default
 library on the same data (and for bit-reproducibility) before it is timed.  Timing as in a scoring step: every launch follows the
 projection's dense layer that writes its z (evo_linear_zg_mfma_bf16 of the default library); events bracket the Hyena launch only;
 the builds are interleaved round by round in ONE process (boxes differ by 25 % in clock)."""
@@ -27,15 +27,15 @@ perm = group_permutation(D, H, dev)
 P = ctypes.c_void_p; I = ctypes.c_int64
 libs = []
 for arg in sys.argv[1:]:
-    old = arg.startswith("old:")
+    old = "old" if arg.startswith("old:") else ("rm" if arg.startswith("rm:") else "")
     name = arg.split(":", 1)[1] if old else arg
     lib = ctypes.CDLL(str(_build.LIBDIR / name))
-    if old:
+    if old == "old":
         fn = lib.evo_hyena_mfma_zg
         fn.argtypes = [P] * 10 + [I] * 4 + [P]
     else:
         fn = lib.evo_hyena_cs_zg
-        fn.argtypes = [P] * 9 + [I] * 6 + [P]
+        fn.argtypes = [P] * 9 + [I] * 8 + [P]
     fn.restype = ctypes.c_int
     libs.append((arg, fn, old))
 st = torch.cuda.current_stream().cuda_stream
@@ -47,22 +47,28 @@ for (B, T) in shapes:
     zg = z[..., perm].view(B * T, D // 16, 48).transpose(0, 1).contiguous()          # [groups, B T, 48]
     nbytes = B * T * D * 8
     y = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
+    yb = ops.yblk_empty(B * T, D, dev)
     sout = torch.zeros(B, D, 8, 2, dtype=torch.float32, device=dev)
 
     def launch(fn, old, want_state=False):
         so = sout.data_ptr() if want_state else None
-        if old:
+        if old == "old":
             rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(), tab.data_ptr(), y.data_ptr(), None, so,
                     poles.data_ptr(), B, T, D, H, st)
-        else:
+        elif old == "rm":
             rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), y.data_ptr(), None, so, poles.data_ptr(),
-                    B, T, D, H, B * T, 0, st)
+                    B, T, D, H, B * T, 0, 0, 0, st)
+        else:
+            rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), yb.data_ptr(), None, so, poles.data_ptr(),
+                    B, T, D, H, B * T, 0, yb.shape[0] * 128, 0, st)
         assert rc == 0, rc
     info = {}
     for (name, fn, old) in libs:
         y.zero_()
         launch(fn, old, True)
         torch.cuda.synchronize()
+        if old == "":
+            y.copy_(ops.yblk_to_rows(yb, B * T).view(B, T, D))
         rl2 = float((y.double() - ref.double()).norm() / ref.double().norm())
         worst = float(((y.double() - ref.double()).abs() - ref.double().abs() * 2.0 ** -7).max() / ref.abs().max())
         srel = float((torch.view_as_complex(sout) - sref).abs().max() / sref.abs().max())
@@ -71,6 +77,8 @@ for (B, T) in shapes:
         for _ in range(3):
             launch(fn, old)
             torch.cuda.synchronize()
+            if old == "":
+                y.copy_(ops.yblk_to_rows(yb, B * T).view(B, T, D))
             same = same and bool(torch.equal(y, y1))
         info[name] = (rl2, worst, srel, same)
         print(f"{B}x{T} {name:28s} vs modal: rel-L2 {rl2:.2e}, worst (|err| - 2^-7|ref|)/max {worst:.1e}, end-state rel {srel:.1e}, "

@@ -29,7 +29,7 @@ for (B, T) in ((8, 8193), (1, 131073)):
         for _ in range(12):
             if mode.startswith("after"):
                 ops.lib.evo_linear_zg_mfma_bf16(xin.data_ptr(), wgt.data_ptr(), None, zg.data_ptr(), Mfull, B * T, 3 * D, D, st)
-            y = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H)
+            y = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
         torch.cuda.synchronize()
         rec = y.view(-1)[:256 * NW * 32].view(torch.float32).view(256, NW, 16).cpu()
         n = rec[0, 0, 5].item()
