@@ -62,8 +62,9 @@ static_assert(HC_LDS <= 160 * 1024, "LDS");
 #define HC_PROFILE 0
 #endif
 #ifndef HC_SPREAD
-#define HC_SPREAD 0                         // 0: the window pieces / stores right behind the barrier (default: measured best with the blocked y);
-                                            // 1: interleaved with the whole tile's arithmetic; 2: the pieces inside the FIR loops
+#define HC_SPREAD 2                         // where a wave issues its window pieces: 2 (default): inside the FIR loops, the first ~40 % of the tile's
+                                            // arithmetic (0.513 / 0.549 of 8 TB/s at 8 x 8,193 / 1 x 131,073 with the blocked y); 0: all right behind
+                                            // the barrier (0.483 / 0.518); 1: spread over the whole tile (they land late: 0.49 / 0.52)
 #endif
 #define HC_YBLK 128                         // rows per block of the BLOCKED y layout (HcArgs.y_blk): [row block][group][128 rows][16 channels]
 #define HC_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)

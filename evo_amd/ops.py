@@ -306,10 +306,11 @@ class HipOps:
         return y
 
     # ---- kernels -------------------------------------------------------------------------------------
-    def embed(self, ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    def embed(self, ids: torch.Tensor, weight: torch.Tensor, validate: bool = True) -> torch.Tensor:
         """Row gather.  Ids outside [0, vocab) raise IndexError (the reference's F.embedding device-asserts): the
         kernel never indexes the table with them and raises a device flag, which is read back here -- except while a
-        hipGraph is being captured (no host read is possible there; the decode loop's ids come from `sample`)."""
+        hipGraph is being captured (no host read is possible there; the decode loop's ids come from `sample`).  `validate=False`: the
+        caller has checked the ids itself (a sequence-parallel rank checks ALL of them before its first collective)."""
         ids = ids.reshape(-1).to(torch.int64).contiguous()
         self._need(ids, torch.int64, "embed ids")
         self._need(weight, torch.bfloat16, "embed weight")
@@ -317,7 +318,7 @@ class HipOps:
         out = torch.empty(ids.numel(), D, dtype=torch.bfloat16, device=weight.device)
         # a fresh 4-byte flag per call (a cached one would be an inference tensor when first made under
         # torch.inference_mode and could not be reset outside it); none while a hipGraph is being captured
-        flag = None if torch.cuda.is_current_stream_capturing() or not self.validate_ids else \
+        flag = None if torch.cuda.is_current_stream_capturing() or not (self.validate_ids and validate) else \
             torch.zeros(1, dtype=torch.int32, device=weight.device)
         _check(self.lib.evo_embed_bf16(ids.data_ptr(), weight.data_ptr(), out.data_ptr(), ids.numel(), D, V,
                                        _ptr(flag), _stream()), "evo_embed_bf16")

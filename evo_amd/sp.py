@@ -509,14 +509,8 @@ class SequenceParallelScorer:
         Tl, t0, t1 = self.shard(T)
         Tloc = t1 - t0
         ops = m.ops
-        keep = getattr(ops, "validate_ids", None)
-        if keep is not None:
-            ops.validate_ids = False                         # (checked above, on every rank)
-        try:
-            h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight)
-        finally:
-            if keep is not None:
-                ops.validate_ids = keep
+        # (checked above, on every rank: no second check -- and no shared flag toggled, ranks may be threads of one process in tests)
+        h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight, validate=False)
         for blk in m.blocks:
             if isinstance(blk, _AttentionBlock):
                 self._attn_block(blk, h, B, Tloc, Tl, t0, T)
