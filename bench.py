@@ -91,15 +91,18 @@ def timed(fn, steps, warmup, dist_on, stats=None):
     return dt
 
 
-def pmc_traffic(kernel, B, T):
+def pmc_traffic(kernel, B, T, with_source=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, see
     profiles/r01_ops_pmc_fetch_write.txt); None for shapes that were not profiled.  PMC counters cannot be
-    collected from inside this process, so this is a recorded measurement, not a live one."""
+    collected from inside this process, so this is a recorded measurement, not a live one: `with_source` also returns
+    the commit the passes were taken at (profiles/pmc_traffic.json "_commit"), printed beside the number."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(kernel, {}).get(f"B{B}_T{T}")
+            d = json.load(f)
+        v = d.get(kernel, {}).get(f"B{B}_T{T}")
+        return (v, d.get("_commit", {}).get(kernel)) if with_source else v
     except (OSError, ValueError):
-        return None
+        return (None, None) if with_source else None
 
 
 def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
@@ -129,17 +132,22 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
     if "hyena_mfma" in ksum:
         ms = ksum["hyena_mfma"][1]
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        zg = "gemm_zg" in ksum                                 # the scoring path fed the operator group-major z (evo_hyena_mfma_zg)
-        return {"kernel": "hyena_mfma_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("hyena_mfma_kernel_zg" if zg else "hyena_mfma_kernel", B, T),
+        zg = "gemm_zg" in ksum                                 # the scoring path fed the operator group-major z
+        cs = zg and getattr(ops, "hyena_cs_flag", False)       # ... and ran the channel-stationary kernel (round 4)
+        kname = "hyena_cs_kernel" if cs else "hyena_mfma_kernel"
+        traffic, t_commit = pmc_traffic(kname if cs else ("hyena_mfma_kernel_zg" if zg else "hyena_mfma_kernel"), B, T, with_source=True)
+        return {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": f"recorded rocprofv3 PMC passes of commit {t_commit} (profiles/pmc_traffic.json), not this run",
                 "z_layout": "group-major [D/16][B T][48], written by the projection's dense layer (one contiguous stream per workgroup)"
                             if zg else "token-major [B][T][3 D]",
+                "y_layout": "blocked [B T / 128][D / 16][128][16] (whole cache lines per store; the output projection's dense layer "
+                            "gathers it)" if cs else "row-major [B T][D]",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                 "tensor_bytes_per_launch": io_live.get("mfma"),
                 "operator_frac": ach / HBM_PEAK_GBS, "modal_three_launch": three,
-                "note": "round 1 reported hyena_apply_kernel, ONE of the operator's three launches (frac 0.55, operator_frac 0.33 over "
-                        "all three); this launch IS the whole operator (z read once, y written once): compare frac with "
-                        "modal_three_launch.operator_frac of the same run"}
+                "note": "one launch IS the whole operator (z read once, y written once: 32,768 B per token and layer); round 1 reported "
+                        "hyena_apply_kernel, one of three launches: compare frac with modal_three_launch.operator_frac of the same run"}
     achieved = alg_bytes / (ksum["hyena_apply"][1] * 1e-3) / 1e9
     op_ms = ksum["hyena_apply"][1] + ksum["hyena_seg_state"][1] + ksum["hyena_carry_scan"][1]
     return {"kernel": "hyena_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -439,19 +447,19 @@ def main():
         "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
     }
-    # ------------------------------------------------------------------ the same step with EVERY dense layer hand-written
-    if n_gpus == 1 and not ops.all_gemm_mfma:
+    # ------------------------------------------------------------------ the same step with the plain dense layers on hipBLASLt
+    if n_gpus == 1 and ops.all_gemm_mfma:
         try:
-            ops.all_gemm_mfma = True
+            ops.all_gemm_mfma = False
             with torch.inference_mode():
                 dt2 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
-            out["all_hand_written_gemm"] = {"value": B * nt / (dt2 / 3), "unit": "nt/s", "ms_per_step": dt2 / 3 * 1e3, "steps": 3,
-                                            "note": "csrc/gemm.hip persistent kernel for all 128 dense layers (EVO_AMD_GEMM=mfma); "
-                                                    "the headline keeps hipBLASLt for the Hyena output projections and l3"}
+            out["library_gemm_l3"] = {"value": B * nt / (dt2 / 3), "unit": "nt/s", "ms_per_step": dt2 / 3 * 1e3, "steps": 3,
+                                      "note": "l3 (32 launches, K = 11,008) on hipBLASLt through torch.addmm in the same process; the headline runs "
+                                              "every dense layer on csrc/gemm.hip (the library is 1-3 % faster on that shape)"}
         except Exception as e:  # noqa: BLE001
-            out["all_hand_written_gemm"] = {"error": f"{type(e).__name__}: {e}"}
+            out["library_gemm_l3"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
-            ops.all_gemm_mfma = False
+            ops.all_gemm_mfma = True
     # ------------------------------------------------------------------ the same step with the gated MLP unfused (the round-2 default)
     if n_gpus == 1 and getattr(ops, "mlp_gate_fused", False):
         try:
@@ -459,16 +467,16 @@ def main():
             with torch.inference_mode():
                 dt3 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
             out["mlp_gate_unfused"] = {"value": B * nt / (dt3 / 3), "unit": "nt/s", "ms_per_step": dt3 / 3 * 1e3, "steps": 3,
-                                       "note": "l1 | l2 on hipBLASLt + the gate kernel (EVO_AMD_MLP_GATE=unfused) in the same process: "
+                                       "note": "l1 | l2 as a plain dense layer + the gate kernel (ops.mlp_gate_fused = False) in the same process: "
                                                "what the one-launch form with GELU * gate in the dense layer's epilogue buys"}
         except Exception as e:  # noqa: BLE001
             out["mlp_gate_unfused"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             ops.mlp_gate_fused = True
-    # ------------------------------------------------------------------ the same step with token-major z for the Hyena operator
-    if n_gpus == 1 and getattr(ops, "hyena_zg", False):
+    # ------------------------------------------------------------------ the same step with the round-3 Hyena kernel
+    if n_gpus == 1 and getattr(ops, "hyena_cs_flag", False):
         try:
-            ops.hyena_zg = False
+            ops.hyena_cs_flag = False
             with torch.inference_mode():
                 dt4 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
                 ops.timer = KernelTimer()
@@ -476,15 +484,15 @@ def main():
                 torch.cuda.synchronize()
                 k4 = ops.timer.summary()
                 ops.timer = None
-            out["hyena_token_major_z"] = {"value": B * nt / (dt4 / 3), "unit": "nt/s", "ms_per_step": dt4 / 3 * 1e3, "steps": 3,
+            out["hyena_round3_kernel"] = {"value": B * nt / (dt4 / 3), "unit": "nt/s", "ms_per_step": dt4 / 3 * 1e3, "steps": 3,
                                           "hyena_mfma_avg_ms": k4.get("hyena_mfma", (0, None))[1],
-                                          "note": "EVO_AMD_HYENA_Z=token in the same process: projection on hipBLASLt into [B, T, 3 D], the operator "
-                                                  "reading a 96-byte slice of every row (the default until the end of round 3)"}
+                                          "note": "the same process with csrc/hyena_mfma.hip (round 3: planes / parked x2 / fp32 y^T through LDS, "
+                                                  "row-major y) instead of csrc/hyena_cs.hip (channel-stationary waves, blocked y)"}
         except Exception as e:  # noqa: BLE001
-            out["hyena_token_major_z"] = {"error": f"{type(e).__name__}: {e}"}
+            out["hyena_round3_kernel"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             ops.timer = None
-            ops.hyena_zg = True
+            ops.hyena_cs_flag = True
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         try:

@@ -173,23 +173,25 @@ def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
     assert err <= floor                                       # never further from fp32 than eager bf16 is
 
 
-@pytest.mark.parametrize("gemm", ["default", "mfma", "unfused"])
+@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "round3_hyena"])
 def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     """(b) BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
     oracle run on that prefix alone (the model is causal) -- end to end, and block by block with the engine's own
     block inputs (teacher-forced), which is the check that is not blurred by 32 layers of bf16 noise.
-    `gemm`: the default routing (plain Hyena / l3 dense layers on hipBLASLt, the gated MLP's first half as one launch of the
-    hand-written dense layer with GELU * gate in its epilogue), EVO_AMD_GEMM=mfma (all 128 dense layers on the hand-written
-    persistent kernel of csrc/gemm.hip, incl. the MLP shapes N = 22,016 and K = 11,008) and EVO_AMD_MLP_GATE=unfused (the
-    round-2 default: library GEMM + gate kernel)."""
+    `gemm`: the default routing (round 4: every dense layer on the hand-written kernel of csrc/gemm.hip -- the Hyena projections
+    with a group-major result, the Hyena output projections gathering the operator's blocked y, the gated MLP's first half with
+    GELU * gate in the epilogue -- launch counts asserted: zero library GEMMs), and the three in-process A/B routings bench.py
+    times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt), `unfused` (dense layer +
+    gate kernel) and `round3_hyena` (ops.hyena_cs_flag = False: csrc/hyena_mfma.hip, row-major y)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P, row = 2049, 3
     ids = acgt_ids(8, 8192)
     m = full["m8"]
     ops = m.ops
-    was, was_gate = ops.all_gemm_mfma, ops.mlp_gate_fused
-    ops.all_gemm_mfma = gemm == "mfma"
+    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag
+    ops.all_gemm_mfma = gemm != "library_l3"
     ops.mlp_gate_fused = gemm != "unfused"
+    ops.hyena_cs_flag = gemm != "round3_hyena"
     if ops.timer is None:
         from evo_amd.ops import KernelTimer
         ops.timer = KernelTimer()
@@ -202,19 +204,18 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
         launches = {k_: n for k_, (n, _) in ops.timer.summary().items()}
     finally:
         m.block_taps = None
-        ops.all_gemm_mfma, ops.mlp_gate_fused = was, was_gate
+        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag = was
         ops.timer = None
-    # the routing under test really ran: no library GEMM launch at all with gemm == "mfma" (the unembed is fused away on the
-    # scoring path only; here `model(ids)` materialises logits through ops.linear -> also the hand-written kernel)
+    # the routing under test really ran (here `model(ids)` materialises logits through ops.linear: one more dense layer than a
+    # scoring step, whose unembedding is fused into the tail kernel)
     print(f"[prefix {gemm}] launches: {launches}")
-    # (29 Hyena projections with a group-major result, 32 gated MLP launches; library: 29 output projections + 32 l3 + the unembed)
-    assert launches.get("gemm_zg", 0) == 29
-    if gemm == "mfma":
-        assert launches.get("gemm", 0) == 0 and launches.get("gemm_mfma", 0) >= 64 and launches.get("gemm_gate", 0) == 32
+    assert launches.get("gemm_zg", 0) == 29 and launches.get("hyena_mfma", 0) == 29
+    if gemm == "library_l3":
+        assert launches.get("gemm", 0) >= 32 and launches.get("gemm_gate", 0) == 32
     elif gemm == "unfused":
-        assert launches.get("gemm", 0) >= 90 and launches.get("gemm_gate", 0) == 0
-    else:
-        assert launches.get("gemm", 0) >= 59 and launches.get("gemm_gate", 0) == 32
+        assert launches.get("gemm", 0) == 0 and launches.get("gemm_gate", 0) == 0 and launches.get("gelu_gate", 0) >= 32
+    else:                                                  # default / round3_hyena: 29 + 32 + 6 + 1 plain launches, 32 gated, no library
+        assert launches.get("gemm", 0) == 0 and launches.get("gemm_mfma", 0) >= 68 and launches.get("gemm_gate", 0) == 32
     assert logits.shape == (8, 8193, 512) and len(taps) == 33
     o = oracle_for(full, FULL, "fp32")
     t0 = time.time()

@@ -1,36 +1,40 @@
 #!/bin/bash
-# Everything a round is judged on, on one MI355X box:  gpurun --timeout 3000 -- 'bash tools/gpu_check.sh'
-#   -m gpu tests, smoke(), bench.py (default flags), the rocprofv3 kernel-trace summaries of the 8k and the 131k scoring step, the PMC
-#   traffic passes of the Hyena operator and the decode kernel-trace -- summaries land in gpurun_out/check/ and are copied to profiles/.
+# Everything a round is judged on, on one MI355X box:  gpurun --timeout 3000 -- 'bash tools/gpu_check.sh [notests|tests]'
+#   -m gpu tests (with -rs and the parity numbers the tests print), smoke(), bench.py (default flags), the rocprofv3 kernel-trace
+#   summaries of the 8k and the 131k scoring step, the PMC traffic passes of the Hyena operator and its SQ counters, the decode
+#   kernel-trace -- summaries land in gpurun_out/check/ and are copied to profiles/rNN_*.
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 R=$PWD
 O=gpurun_out/check; mkdir -p $O
 # (no EVO_AMD_NO_REBUILD here: ops.py rebuilds a library that is older than its sources, so the checks run the HEAD kernels)
 if [ "$1" != "notests" ]; then
-timeout 2400 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed" $O/gpu_tests.log | tail -2
+timeout 2400 python -m pytest tests -m gpu -q -s -rs > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; grep -E "passed|failed" $O/gpu_tests.log | tail -2
+grep -E "^\.*\[" $O/gpu_tests.log | sed 's/^\.*//' | cut -c1-1600 > $O/gpu_tests_parity_lines.txt; grep -E "SKIPPED|passed|failed" $O/gpu_tests.log | tail -20 >> $O/gpu_tests_parity_lines.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log
 fi
+if [ "$1" == "tests" ]; then exit 0; fi
 timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o b -- python $R/bench.py --skip-131k --skip-cpu --skip-gen --steps 3 --warmup 1 > $R/$O/prof_bench.log 2>&1
 cd $R && python tools/summarize_prof.py stats $O/prof > $O/bench_8k_kernel_stats.txt && rm -rf $O/prof
-head -12 $O/bench_8k_kernel_stats.txt
+head -14 $O/bench_8k_kernel_stats.txt
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof131 -o p -- python $R/tools/profile_131k.py > $R/$O/prof_131k.log 2>&1
 cd $R && python tools/summarize_prof.py stats $O/prof131 > $O/bench_131k_kernel_stats.txt && rm -rf $O/prof131
-head -12 $O/bench_131k_kernel_stats.txt
-# HBM-side traffic of the Hyena operator: separate counter passes (no trace domains beside --kernel-trace)
-cd /tmp
-timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_rd -o r -- python $R/tools/bench_ops.py --only hyena --reps 2 > $R/$O/pmc_rd.log 2>&1
-timeout 600 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_wr -o w -- python $R/tools/bench_ops.py --only hyena --reps 2 > $R/$O/pmc_wr.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/pmc_rd; python tools/summarize_prof.py pmc $O/pmc_wr) > $O/hyena_pmc_traffic.txt; rm -rf $O/pmc_rd $O/pmc_wr
-grep -i "mfma" $O/hyena_pmc_traffic.txt
-# ... and of its group-major launch (evo_hyena_mfma_zg: the scoring path's default)
+head -14 $O/bench_131k_kernel_stats.txt
+# HBM-side traffic of the Hyena operator as the scoring path launches it (hyena_cs: group-major z, blocked y): separate counter
+# passes (no trace domains beside --kernel-trace)
 cd /tmp
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zrd -o r -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zrd.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zwr -o w -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zwr.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_mfma" > $O/hyena_zg_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
-cat $O/hyena_zg_pmc_traffic.txt
+cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_cs" > $O/hyena_cs_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
+cat $O/hyena_cs_pmc_traffic.txt
+# SQ counters of the same launches (instruction mix, LDS activity / bank conflicts, wait states)
+cd /tmp
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq1 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq2 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq2.log 2>&1
+cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_cs" > $O/hyena_cs_sq_counters.txt; rm -rf $O/sq1 $O/sq2
+cat $O/hyena_cs_sq_counters.txt | cut -c1-200
 # the same for a decode run (BASELINE configs[4] shape: 8,192-nt prompt, greedy): per-kernel times of the generation leg
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/profg -o g -- python $R/tools/bench_generate.py --new 128 > $R/$O/prof_gen.log 2>&1

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""The single-pass Hyena operator on GROUP-MAJOR z alone (for rocprofv3 --pmc passes): 3 launches at 8 x 8,193 x 4096, then 3 at 1 x 131,073 x 4096."""
+"""The single-pass Hyena operator as the scoring path launches it (csrc/hyena_cs.hip: group-major z in, blocked y out) alone, for
+rocprofv3 --pmc passes: 3 launches at 8 x 8,193 x 4096, then 3 at 1 x 131,073 x 4096."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +18,6 @@ dskip = rn(D, std=0.5).bfloat16(); tab = mfma_operand_table(poles, res, dskip)
 for (B, T) in ((8, 8193), (1, 131073)):
     zg = rn(D // 16, B * T, 48).bfloat16()
     for _ in range(3):
-        ops.hyena_mfma_prefill(zg, fir_w, fir_b, dskip, tab, H, zg_shape=(B, T))
+        ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
     torch.cuda.synchronize()
 print("done")
