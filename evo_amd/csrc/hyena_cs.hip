@@ -399,6 +399,10 @@ __device__ __forceinline__ void hc_run(const HcArgs& a, unsigned char* smem) {
                 }
             }
             HC_VMP(2 + 2 * pp);
+            if (SO) {                                        // (no x2 loop in the state-only walk: its pieces go out here)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) HC_VMF(7 * pp + 4 + i);
+            }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 uint32_t hw[4];
