@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nt", type=int, default=8192)
     ap.add_argument("--skip-131k", action="store_true")
+    ap.add_argument("--skip-ab", action="store_true", help="skip the in-process A/B legs (library_gemm_l3, mlp_gate_unfused, hyena_round3_kernel): "
+                                                          "the profile runs want the headline step's kernels only")
     ap.add_argument("--skip-sp-predict", action="store_true", help="skip the stub-communicator rank of configs[3] (scaling_131k_predicted)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-gen", action="store_true")
@@ -448,7 +450,7 @@ def main():
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
     }
     # ------------------------------------------------------------------ the same step with the plain dense layers on hipBLASLt
-    if n_gpus == 1 and ops.all_gemm_mfma:
+    if n_gpus == 1 and ops.all_gemm_mfma and not args.skip_ab:
         try:
             ops.all_gemm_mfma = False
             with torch.inference_mode():
@@ -461,7 +463,7 @@ def main():
         finally:
             ops.all_gemm_mfma = True
     # ------------------------------------------------------------------ the same step with the gated MLP unfused (the round-2 default)
-    if n_gpus == 1 and getattr(ops, "mlp_gate_fused", False):
+    if n_gpus == 1 and getattr(ops, "mlp_gate_fused", False) and not args.skip_ab:
         try:
             ops.mlp_gate_fused = False
             with torch.inference_mode():
@@ -474,7 +476,7 @@ def main():
         finally:
             ops.mlp_gate_fused = True
     # ------------------------------------------------------------------ the same step with the round-3 Hyena kernel
-    if n_gpus == 1 and getattr(ops, "hyena_cs_flag", False):
+    if n_gpus == 1 and getattr(ops, "hyena_cs_flag", False) and not args.skip_ab:
         try:
             ops.hyena_cs_flag = False
             with torch.inference_mode():

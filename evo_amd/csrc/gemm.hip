@@ -867,15 +867,15 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
     return evo_launch_status();
 }
 
-// y [M, N] = x . w^T + residual with x in the BLOCKED layout the channel-stationary Hyena operator writes
+// y [M, N] = x . w^T (+ bias) (+ residual) with x in the BLOCKED layout the channel-stationary Hyena operator writes
 // ([ceil(M / 128)][K / 16][128][16] bf16): the Hyena block's output projection [REF stripedhyena/model.py ParallelGatedConvBlock.forward:
 // out_filter_dense].  M % 256 == 0 (the caller peels the BOS sliver), K % 64 == 0, K >= 128.
-extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* residual, void* y,
+extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
                                          int64_t M, int64_t N, int64_t K, void* stream) {
     if (M <= 0 || M % GBM != 0 || N <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || K < 2 * GBK || N > 0x7fffffff / 2) return -1;
     if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
-    a.x = (const unsigned char*)x_blk; a.w = (const unsigned char*)w; a.bias = nullptr;
+    a.x = (const unsigned char*)x_blk; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias;
     a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
     a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = M;
     a.tiles_n = (int)(N / GBN);
@@ -891,7 +891,9 @@ extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const
         return n < 8 ? 8 : n;
     }();
     const dim3 gridp((unsigned)n_cu), block4(256);
-    if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
+    if (bias && residual) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
+    else if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
+    else if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }

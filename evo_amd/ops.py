@@ -39,7 +39,7 @@ _SIGNATURES = {
     "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 8 + [_PTR], _c.c_int),
-    "evo_linear_xblk_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_linear_xblk_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -250,19 +250,17 @@ class HipOps:
         weight-streaming kernel adds it in the same pass."""
         if self._use_small_m(x, w) and res.is_contiguous():
             return self._linear_small_m(x, w, bias, res)
-        if bias is not None:
-            self.linear_residual_(res, x, w, mfma)
-            return res.add_(bias)
         r = self._tail_rows(x, w) if res.is_contiguous() else 0
         if r:
             M = x.shape[0]
-            self.linear_residual_(res[: M - r], x[: M - r], w, mfma)
-            self._linear_small_m(x[M - r:], w, None, res[M - r:])
+            self.linear_residual_(res[: M - r], x[: M - r], w, mfma, bias=bias)
+            self._linear_small_m(x[M - r:], w, bias, res[M - r:])
             return res
         if self._take_mfma(mfma) and self.mfma_linear_ok(x, w) and res.is_contiguous():
-            return self.linear_mfma(x, w, None, res)
+            return self.linear_mfma(x, w, bias, res)          # (bias and residual in the dense layer's epilogue: one rounding)
         with self._t("gemm"):
-            return res.addmm_(x, w.t())
+            res.addmm_(x, w.t())
+        return res if bias is None else res.add_(bias)
 
     @staticmethod
     def _use_small_m(x, w):
@@ -555,8 +553,8 @@ class HipOps:
         self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}
         return (y, torch.view_as_complex(s_fin)) if want_state else y
 
-    def linear_residual_yblk_(self, res: torch.Tensor, y_blk: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-        """res [M, N] += y @ w^T with y given BLOCKED (hyena_cs's y_blk: [ceil(M / 128), K / 16, 128, 16]) -- the Hyena block's output
+    def linear_residual_yblk_(self, res: torch.Tensor, y_blk: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """res [M, N] += y @ w^T (+ bias, in the same epilogue: one rounding) with y given BLOCKED (hyena_cs's y_blk: [ceil(M / 128), K / 16, 128, 16]) -- the Hyena block's output
         projection on the hand-written dense layer (csrc/gemm.hip, X operand gathered from the blocked form); the last M % 256
         rows (the BOS sliver) go row-major through the weight-streaming kernel, as everywhere."""
         M, N = res.shape
@@ -566,15 +564,15 @@ class HipOps:
         ok = (Mf > 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and Mf * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff
               and w.dtype == torch.bfloat16 and w.is_contiguous())
         if not ok:
-            return self.linear_residual_(res, self.yblk_to_rows(y_blk, M).contiguous(), w)
+            return self.linear_residual_(res, self.yblk_to_rows(y_blk, M).contiguous(), w, bias=bias)
         with self._t("gemm_mfma"):
-            _check(self.lib.evo_linear_xblk_mfma_bf16(y_blk.data_ptr(), w.data_ptr(), res.data_ptr(), res.data_ptr(), Mf, N, K, _stream()),
-                   "evo_linear_xblk_mfma_bf16")
+            _check(self.lib.evo_linear_xblk_mfma_bf16(y_blk.data_ptr(), w.data_ptr(), _ptr(bias), res.data_ptr(), res.data_ptr(), Mf, N, K,
+                                                      _stream()), "evo_linear_xblk_mfma_bf16")
         if M > Mf:                                           # (<= 255 rows: rows Mf .. M - 1 of the matrix, gathered row-major)
             r = M - Mf
             nb0 = Mf // self.YBLK
             tail = y_blk[nb0:].permute(0, 2, 1, 3).reshape(-1, K)[:r].contiguous()
-            self.linear_residual_(res[Mf:], tail, w)
+            self.linear_residual_(res[Mf:], tail, w, bias=bias)
         return res
 
     def hyena_mfma_state(self, z, fir_w, fir_b, table, n_heads, poles, z_halo=None, s0=None) -> torch.Tensor:

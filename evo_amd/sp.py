@@ -402,10 +402,10 @@ class SequenceParallelScorer:
             else:
                 y = yg
         if zgm:
-            ops.linear_residual_yblk_(x2d, y, blk.out_filter_dense.weight)
+            ops.linear_residual_yblk_(x2d, y, blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)
         else:
-            ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight)
-        m._mlp_residual_(blk, x2d, blk.out_filter_dense.bias)
+            ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)
+        m._mlp_residual_(blk, x2d, None)                     # (the bias went into the output projection's epilogue, as in model.py)
 
     def _attn_block(self, blk, x2d, B, Tloc, Tl, t0, T):
         m, ops = self.m, self.m.ops
@@ -419,8 +419,8 @@ class SequenceParallelScorer:
             a = self._attn_ulysses(qkv, B, Tloc, Tl, T)
         else:
             a = self._attn_allgather(qkv, B, Tloc, Tl, t0)
-        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight, mfma=True)
-        m._mlp_residual_(blk, x2d, mha.out_proj.bias)
+        ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight, mfma=True, bias=mha.out_proj.bias)
+        m._mlp_residual_(blk, x2d, None)
 
     def _attn_ulysses(self, qkv, B, Tloc, Tl, T):
         """Batch rows travel in `attn_row_groups` groups: ONE all-to-all and ONE attention launch (rows x H/R heads) per group

@@ -147,9 +147,9 @@ int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const 
                     int64_t z_group_rows, int64_t state_only, int64_t y_blocked_rows, int64_t y_row0, void* stream);
 
 /* The Hyena block's output projection on the blocked y of evo_hyena_cs_zg            [REF stripedhyena/model.py ParallelGatedConvBlock:
- * out_filter_dense]:  y [M, N] = x . w^T (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense
+ * out_filter_dense]:  y [M, N] = x . w^T (+ bias [N]) (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense
  * layer of evo_linear_mfma_bf16 with other source addresses for its X tiles; M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128. */
-int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* residual, void* y,
+int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
                               int64_t M, int64_t N, int64_t K, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------

@@ -247,10 +247,11 @@ def test_output_projection_on_the_blocked_hyena_output_is_the_row_major_dense_la
     pad[:M] = y
     y_blk = pad.view(nrb, 128, K // 16, 16).permute(0, 2, 1, 3).contiguous()
     assert torch.equal(ops.yblk_to_rows(y_blk, M), y)
-    got = ops.linear_residual_yblk_(res.clone(), y_blk, w)
+    bias = torch.randn(N, generator=g, device=DEV).bfloat16() if N <= 512 else None          # (with and without the epilogue's bias)
+    got = ops.linear_residual_yblk_(res.clone(), y_blk, w, bias=bias)
     Mf = M // 256 * 256
-    want = ops.linear_mfma(y[:Mf].contiguous(), w, None, res[:Mf].clone())
+    want = ops.linear_mfma(y[:Mf].contiguous(), w, bias, res[:Mf].clone())
     assert torch.equal(got[:Mf], want)
-    ref = (y.double() @ w.double().t() + res.double())
+    ref = (y.double() @ w.double().t() + res.double()) + (0 if bias is None else bias.double())
     err = (got.double() - ref).abs()
     assert (err <= ref.abs() * 2.0 ** -8 + 2e-3 * float(ref.abs().max())).all()

@@ -15,7 +15,7 @@ fi
 if [ "$1" == "tests" ]; then exit 0; fi
 timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o b -- python $R/bench.py --skip-131k --skip-cpu --skip-gen --steps 3 --warmup 1 > $R/$O/prof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o b -- python $R/bench.py --skip-131k --skip-cpu --skip-gen --skip-ab --steps 3 --warmup 1 > $R/$O/prof_bench.log 2>&1
 cd $R && python tools/summarize_prof.py stats $O/prof > $O/bench_8k_kernel_stats.txt && rm -rf $O/prof
 head -14 $O/bench_8k_kernel_stats.txt
 cd /tmp
