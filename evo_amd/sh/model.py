@@ -200,22 +200,21 @@ class StripedHyena(nn.Module):
             blk.mlp._w12 = w12
             blk.mlp._w3 = w3
             # the same rows regrouped for the one-launch gated form of the prefill path (GELU * gate in the dense layer's epilogue:
-            # csrc/gemm.hip); a copy (180 MB per layer at D = 4096: 5.8 GB for 32 layers) -- the decode kernels stream `w12` as it is
+            # csrc/gemm.hip) are a copy (180 MB per layer at D = 4096: 5.8 GB for 32 layers; the decode kernels stream `w12` as it is):
+            # built on the first prefill-sized call (_gate_pack), so that decode-only use never pays for it
             blk.mlp._w12g = None
-            if getattr(self.ops, "mlp_gate_fused", False) and (2 * ipad) % 256 == 0 and ipad % 32 == 0 and D_ % 64 == 0 and D_ >= 128:
-                blk.mlp._w12g = self.ops.pack_gate_weights(w12)
+            blk.mlp._w12g_ok = (2 * ipad) % 256 == 0 and ipad % 32 == 0 and D_ % 64 == 0 and D_ >= 128
             if isinstance(blk, _HyenaBlock):
                 f = blk.filter
                 D = self.hidden_size
                 f._fir_w = f.short_filter_weight.data.reshape(3 * D, self.short_filter_length).contiguous()
                 f._poles = f.poles.data.reshape(D, self.state_size, 2).float().contiguous()
                 f._residues = f.residues.data.reshape(D, self.state_size, 2).float().contiguous()
-                f._mfma = None                   # grouped projection + operand table of the matrix-core operator
-                if getattr(self.ops, "hyena_mfma", False) and D == self.num_heads * 128:
-                    # built here, with the other derived layouts (not inside a later, possibly timed, forward): a row-permuted
-                    # copy of the projection weight (100 MB per layer at D = 4096) and the [D,52,64] operand table (54 MB) --
-                    # 4.5 GB for the 29 Hyena layers of the 7B model, beside the 12.9 GB of weights
-                    self._mfma_pack(blk)
+                # grouped projection + operand table of the matrix-core operator: a row-permuted copy of the projection weight (100 MB
+                # per layer at D = 4096) and the [D,52,64] operand table (54 MB) -- 4.5 GB for the 29 Hyena layers of the 7B model,
+                # beside the 12.9 GB of weights; built by _mfma_pack on the first parallel Hyena call of the layer
+                # (every bench / test does untimed warm-up passes first), never for decode-only use
+                f._mfma = None
         self._packed = True
 
     # ------------------------------------------------------------------ caches
@@ -293,8 +292,17 @@ class StripedHyena(nn.Module):
         self.ops.linear_residual_(x2d, y, w, mfma=mfma, bias=bias)
         return None
 
+    def _gate_pack(self, blk, M: int):
+        """The regrouped l1 | l2 weight of the one-launch gated MLP, built the first time a prefill-sized batch needs it."""
+        mlp = blk.mlp
+        if mlp._w12g is None and M >= 256 and getattr(mlp, "_w12g_ok", False) and getattr(self.ops, "mlp_gate_fused", False) \
+                and hasattr(self.ops, "pack_gate_weights"):
+            mlp._w12g = self.ops.pack_gate_weights(mlp._w12)
+        return mlp._w12g
+
     def _mlp_residual_(self, blk, x2d, bias, mask=None):
         ops = self.ops
+        self._gate_pack(blk, x2d.shape[0])
         if mask is not None:                                             # upstream: (mixer out + u) * padding_mask
             if bias is not None:
                 x2d.add_(bias)

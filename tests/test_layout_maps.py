@@ -82,3 +82,105 @@ def test_plane_layouts_are_one_formula():
             owners = {used[x][0] >> 3 for x in range(b, b + 16)}
             assert owners == {q >> 1}, (US, q, owners)
         assert XTCH % 16 == 0
+
+
+# ---- round 4: csrc/hyena_cs.hip and the blocked-X dense layer ----------------------------------------------------------------
+def test_hyena_cs_window_image_and_bank_spread():
+    """The LDS image of a tile's z window: 16 blocks of 32 rows x 96 B + a 16-byte pad, filled by 49 one-KiB DMA pieces (lane l of
+    piece p writes LDS byte 1024 p + 16 l).  Every (row, signal, quad) a lane reads must hold the stream bytes the kernel thinks it
+    holds; a ds_read_b64 of the 32 lanes of a group lands on all 64 banks twice (2-way: the floor for 8 bytes out of 16-byte granules)."""
+    import collections
+    BLKB = 32 * 96 + 16
+
+    def dma_off(o):                                       # hyena_cs.hip: dma_off[] (source byte of the lane's chunk within the tile)
+        blk, within = divmod(o, BLKB)
+        return 32 * 96 * blk + (within if within < 32 * 96 else 32 * 96 - 16)
+    src = {1024 * p + 16 * l: dma_off(1024 * p + 16 * l) for p in range(49) for l in range(64)}
+    for r in range(512):
+        for s in range(3):
+            for q4 in range(4):
+                a = r * 96 + (r >> 5) * 16 + 32 * s + 8 * q4
+                assert src[a & ~15] + (a & 15) == r * 96 + 32 * s + 8 * q4
+    assert max(src) + 16 <= 49 * 1024
+    for la in range(16):                                  # a lane's ten rows: two of history, eight of its own
+        for lq in range(4):
+            main = (32 * la + 8 * lq) * 96 + la * 16
+            hist = main - 192 if lq else (main - 192 - 16 if la else None)
+            for i in range(10):
+                r = 32 * la + 8 * lq + i - 2
+                if r < 0:
+                    continue                              # (block 0: the halo slot)
+                addr = (hist + i * 96) if i < 2 else main + (i - 2) * 96
+                assert addr == r * 96 + (r >> 5) * 16
+    for i in range(2, 10):
+        for grp in range(2):
+            banks = collections.Counter()
+            for lane in range(32 * grp, 32 * grp + 32):
+                la, lq = lane & 15, lane >> 4
+                a = (32 * la + 8 * lq) * 96 + la * 16 + (i - 2) * 96
+                for d in range(2):
+                    banks[(a // 4 + d) % 64] += 1
+            assert max(banks.values()) == 2
+
+
+def test_hyena_cs_row_permutation_of_the_operand_tables():
+    """T0 / G rows as hyena_cs.hip loads them: logical row 16 mt + la (la = 4 q + r) of the kernel = step 8 q + 4 mt + r of the block =
+    row 8 (q & 1) + 4 mt + r of the table's M tile q >> 1.  Then the accumulators of lane (block, lq) -- rows 4 lq + r of both M tiles --
+    are its own eight steps 8 lq + 4 mt + r, and the map is a permutation of the 32 steps."""
+    steps = []
+    for mt in range(2):
+        for la in range(16):
+            q, r = la >> 2, la & 3
+            src_mt, src_row = q >> 1, 8 * (q & 1) + 4 * mt + r
+            step = 16 * src_mt + src_row
+            assert step == 8 * q + 4 * mt + r
+            steps.append(step)
+    assert sorted(steps) == list(range(32))
+    for lq in range(4):
+        own = sorted(8 * lq + 4 * mt + r for mt in range(2) for r in range(4))
+        assert own == list(range(8 * lq, 8 * lq + 8))
+
+
+def test_blocked_y_layout_and_the_dense_layers_gather():
+    """y blocked = [row block of 128][K / 16 groups][128 rows][16 channels].  (1) the byte hyena_cs.hip stores row R, group cg at;
+    (2) HipOps.yblk_to_rows / zg_rows / zg_set_rows invert the layouts; (3) csrc/gemm.hip (XB): the lane that fills 16-byte granule
+    s of LDS row r of an X slab (rows m0 .. m0 + 255, channels 64 k .. 64 k + 63) fetches exactly that row's channels 8 s' .. 8 s' + 7
+    (s' = the swizzled granule), with voffset = lane part, soffset = m0 * K * 2 + k * 16,384."""
+    import torch
+    from evo_amd.ops import HipOps
+    K, M = 256, 700
+    G = K // 16
+    y = torch.arange(M * K, dtype=torch.float32).view(M, K)
+    nrb = (M + 127) // 128
+    pad = torch.zeros(nrb * 128, K)
+    pad[:M] = y
+    y_blk = pad.view(nrb, 128, G, 16).permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(HipOps.yblk_to_rows(y_blk, M), y)
+    flat = y_blk.reshape(-1)
+    for R in (0, 1, 127, 128, 300, 699):
+        for cg in (0, 3, G - 1):
+            off = ((R // 128) * G + cg) * (128 * 16) + (R % 128) * 16          # element offset of (row R, channel 16 cg)
+            assert flat[off].item() == y[R, 16 * cg].item() and flat[off + 15].item() == y[R, 16 * cg + 15].item()
+    # the dense layer's X-tile gather (bytes; bf16 = 2 B per element)
+    kb = K * 2
+    for m0 in (0, 256):
+        for k in range(K // 64):
+            soff = m0 * kb + k * 16384
+            for wave in range(4):
+                for lane in range(64):
+                    r0 = 8 * wave + (lane >> 3)
+                    xs = ((lane & 7) ^ r0) & 7
+                    voff0 = r0 * 32 + (xs >> 1) * 4096 + (xs & 1) * 16
+                    for jj in range(8):
+                        voff = voff0 + (jj & 3) * 1024 + (jj >> 2) * 128 * kb
+                        row, ch = m0 + r0 + 32 * jj, 64 * k + 8 * xs                # what LDS row r0 + 32 jj, granule slot lane & 7 must hold
+                        want = (((row // 128) * G + ch // 16) * (128 * 16) + (row % 128) * 16 + ch % 16) * 2
+                        assert soff + voff == want, (m0, k, wave, lane, jj)
+    # group-major z helpers
+    B, T = 3, 5
+    zt = torch.arange(B * T * 3 * 32, dtype=torch.float32).view(B, T, 96)
+    zg = zt.view(B * T, 2, 48).transpose(0, 1).contiguous()
+    assert torch.equal(HipOps.zg_rows(zg, B, T, 3, 2), zt[:, 3:5])
+    z2 = torch.zeros_like(zg)
+    HipOps.zg_set_rows(z2, B, T, 0, zt)
+    assert torch.equal(z2, zg)
