@@ -132,15 +132,18 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
     if "hyena_mfma" in ksum:
         ms = ksum["hyena_mfma"][1]
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        zg = "gemm_zg" in ksum                                 # the scoring path fed the operator group-major z
-        cs = zg and getattr(ops, "hyena_cs_flag", False)       # ... and ran the channel-stationary kernel (round 4)
-        kname = "hyena_cs_kernel" if cs else "hyena_mfma_kernel"
+        ct = "gemm_zt" in ksum                                 # the scoring path fed the operator channel-major z^T (round 4, second form)
+        zg = "gemm_zg" in ksum                                 # ... or group-major z
+        cs = ct or (zg and getattr(ops, "hyena_cs_flag", False))   # channel-stationary waves, blocked y (round 4)
+        kname = "hyena_ct_kernel" if ct else ("hyena_cs_kernel" if cs else "hyena_mfma_kernel")
         traffic, t_commit = pmc_traffic(kname if cs else ("hyena_mfma_kernel_zg" if zg else "hyena_mfma_kernel"), B, T, with_source=True)
         return {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": f"recorded rocprofv3 PMC passes of commit {t_commit} (profiles/pmc_traffic.json), not this run",
-                "z_layout": "group-major [D/16][B T][48], written by the projection's dense layer (one contiguous stream per workgroup)"
-                            if zg else "token-major [B][T][3 D]",
+                "z_layout": ("channel-major z^T [3 D][B Tp], written by the projection's dense layer launched with swapped operands (a lane's eight "
+                             "steps of a channel = 16 contiguous bytes, loaded straight into registers: no window in LDS)") if ct else
+                            ("group-major [D/16][B T][48], written by the projection's dense layer (one contiguous stream per workgroup)"
+                             if zg else "token-major [B][T][3 D]"),
                 "y_layout": "blocked [B T / 128][D / 16][128][16] (whole cache lines per store; the output projection's dense layer "
                             "gathers it)" if cs else "row-major [B T][D]",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
@@ -423,14 +426,14 @@ def main():
     kernels["attn_fwd"]["mfma_frac"] = kernels["attn_fwd"]["tflops"] / MFMA_BF16_PEAK_TFLOPS
     # dense layers: "gemm" = hipBLASLt, "gemm_mfma" = the hand-written kernel (csrc/gemm.hip), "gemm_gate" = the same kernel with the
     # gated MLP's GELU * gate in its epilogue (l1 | l2 of every block; its launch also does the work of the former gelu_gate pass)
-    gemm_ms = sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm", "gemm_mfma", "gemm_gate", "gemm_zg") if k in ksum)
+    gemm_ms = sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm", "gemm_mfma", "gemm_gate", "gemm_zg", "gemm_zt") if k in ksum)
     # the dense layers (87 % of the step) against the dense bf16 MFMA peak: 2 * M * N * K summed over the launches of a step
     dense_flop = 2.0 * B * T * 4096 * (12288 + 4096 + 22016 + 11008) * 32      # proj/Wqkv, out, l1|l2 (padded), l3 (padded K)
     roofline_dense = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "achieved": dense_flop / (gemm_ms * 1e-3) / 1e12, "frac": dense_flop / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                       "kernels": "hipBLASLt MT256x256x64 (Hyena output projections, l3) + gemmr_bf16_kernel (attention projections; l1 | l2 with "
                                  "GELU * gate in the epilogue; Hyena projections with a group-major result)" if "gemm" in ksum else "gemmr_bf16_kernel (csrc/gemm.hip)", "ms_per_step": gemm_ms,
-                      "hand_written_share_of_dense_ms": sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm_mfma", "gemm_gate", "gemm_zg") if k in ksum) / gemm_ms,
+                      "hand_written_share_of_dense_ms": sum(ksum[k][1] * ksum[k][0] / args.steps for k in ("gemm_mfma", "gemm_gate", "gemm_zg", "gemm_zt") if k in ksum) / gemm_ms,
                       "note": "2.5 PFLOP/s is the dense peak; the part is power-limited: both kernels run their MFMA pipes 82-86 % busy "
                               "at 1.6-1.7 GHz (profiles/r03_gemm_notes.txt)"}
     out = {
@@ -475,10 +478,32 @@ def main():
             out["mlp_gate_unfused"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             ops.mlp_gate_fused = True
+    # ------------------------------------------------------------------ the same step with the group-major form of this round's kernel
+    if n_gpus == 1 and getattr(ops, "hyena_ct_flag", False) and not args.skip_ab:
+        try:
+            ops.hyena_ct_flag = False
+            with torch.inference_mode():
+                dt5 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+                ops.timer = KernelTimer()
+                scoring_step(model, ids)
+                torch.cuda.synchronize()
+                k5 = ops.timer.summary()
+                ops.timer = None
+            out["hyena_group_major_kernel"] = {"value": B * nt / (dt5 / 3), "unit": "nt/s", "ms_per_step": dt5 / 3 * 1e3, "steps": 3,
+                                               "hyena_mfma_avg_ms": k5.get("hyena_mfma", (0, None))[1],
+                                               "projection_avg_ms": k5.get("gemm_zg", (0, None))[1],
+                                               "note": "the same process with csrc/hyena_cs.hip on group-major z (window DMA'd into LDS, 30 "
+                                                       "conflicted ds_read_b64 per wave and tile) instead of csrc/hyena_ct.hip on z^T"}
+        except Exception as e:  # noqa: BLE001
+            out["hyena_group_major_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.timer = None
+            ops.hyena_ct_flag = True
     # ------------------------------------------------------------------ the same step with the round-3 Hyena kernel
     if n_gpus == 1 and getattr(ops, "hyena_cs_flag", False) and not args.skip_ab:
         try:
             ops.hyena_cs_flag = False
+            ops.hyena_ct_flag = False
             with torch.inference_mode():
                 dt4 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
                 ops.timer = KernelTimer()
@@ -495,6 +520,7 @@ def main():
         finally:
             ops.timer = None
             ops.hyena_cs_flag = True
+            ops.hyena_ct_flag = True
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         try:

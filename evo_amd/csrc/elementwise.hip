@@ -53,7 +53,7 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 template <bool HAS_BIAS, int NV>   // NV = register-cached 16-byte vectors per lane (row <= NV*512 elements)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
                                                       const uint4* __restrict__ scale, uint4* __restrict__ out,
-                                                      int64_t M, int nvec, float eps, float inv_sqrt_d) {
+                                                      int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t pad) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, con
         }
         ss = wave_sum(ss);
         const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
-        uint4* orow = out + row * nvec;
+        // (evo_rmsnorm_rows_bf16: batch row b = row / T of the output starts at position b * (T + pad))
+        uint4* orow = out + (row + (T ? row / T * pad : 0)) * nvec;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int idx = lane + 64 * i;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, con
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
                                                            const uint4* __restrict__ scale, uint4* __restrict__ out,
-                                                           int64_t M, int nvec, float eps, float inv_sqrt_d) {
+                                                           int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t pad) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x
         }
         ss = wave_sum(ss);
         const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
-        uint4* orow = out + row * nvec;
+        uint4* orow = out + (row + (T ? row / T * pad : 0)) * nvec;
         for (int idx = lane; idx < nvec; idx += 64) {
             float f[8], s[8];
             unpack8(xr[idx], f);
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x
     }
 }
 
-extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D,
-                                float eps, void* stream) {
+static int rmsnorm_launch(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps, int64_t T,
+                          int64_t pad, void* stream) {
     if (D % 8 != 0 || D <= 0 || M < 0) return -1;
     if (M == 0) return 0;
     int nvec = (int)(D / 8);
@@ -146,7 +147,7 @@ extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, vo
     hipStream_t s = (hipStream_t)stream;
 #define EVO_RMS_LAUNCH(K)                                                                                          \
     hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, s, (uint4*)x, (const uint4*)bias, (const uint4*)scale,        \
-                       (uint4*)out, M, nvec, eps, isd)
+                       (uint4*)out, M, nvec, eps, isd, T, pad)
     if (nvec <= 64 * 2) {
         if (bias) EVO_RMS_LAUNCH((rmsnorm_kernel<true, 2>)); else EVO_RMS_LAUNCH((rmsnorm_kernel<false, 2>));
     } else if (nvec <= 64 * 8) {
@@ -156,6 +157,20 @@ extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, vo
     }
 #undef EVO_RMS_LAUNCH
     return evo_launch_status();
+}
+
+extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D,
+                                float eps, void* stream) {
+    return rmsnorm_launch(x, bias, scale, out, M, D, eps, 0, 0, stream);
+}
+
+// The same norm with the output rows of every batch row of T tokens placed at a pitch of Tp >= T rows (out [B * Tp, D]; the pad rows
+// are not written): the input form of the swapped-operand Hyena projection, whose result z^T wants every batch row to start at a
+// multiple of 8 positions (csrc/hyena_ct.hip).  M = B * T rows of x.
+extern "C" int evo_rmsnorm_rows_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps,
+                                     int64_t T, int64_t Tp, void* stream) {
+    if (T <= 0 || Tp < T || M % T != 0) return -1;
+    return rmsnorm_launch(x, bias, scale, out, M, D, eps, T, Tp - T, stream);
 }
 
 // ------------------------------------------------------------------------------------------- rope

@@ -352,7 +352,8 @@ static_assert(!GE_FULL || GE_ORDER == 1, "GE_FULL pairs the strips of GE_ORDER 1
 //   [row block of 128][K / 16 groups][128 rows][16 channels] bf16 -- a 64-channel slab of a row is four 32-byte pieces 4 KiB apart
 //   instead of one 128-byte piece; only the DMA's SOURCE addresses change (the lane that fills granule s of LDS row r fetches
 //   32-byte piece s >> 1, half s & 1), the k-step is 16 KiB instead of 128 B; the tile origin m0 * K * 2 is the same number.
-template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; 2: group-major z for the Hyena operator
+template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; 2: group-major z for the Hyena operator;
+                                                            // 3: y [M, N] with the bias indexed by ROW (the swapped-operand launch: evo_linear_t_mfma_bf16)
 __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     constexpr uint32_t XSTEP = XB ? 16384u : (uint32_t)(GBK * 2);   // bytes from one k-step's X slab to the next
     __shared__ __attribute__((aligned(16))) unsigned char smem[G_NSLOT * G_SLAB];   // the ONLY __shared__ object
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     // whole-line form: row (l15 & 7) of an 8-row group, byte 64 (l15 >> 3) + 16 lq of the 128-byte line of a strip pair
     const uint32_t ep_voff_f = (uint32_t)((wm * 128 + (l15 & 7)) * a.N + wn * 128 + 8 * lq + 32 * (l15 >> 3)) * 2u;
     const uint32_t ep_boff = (uint32_t)(wn * 128 + 8 * lq) * 2u;        // bias: this lane's eight columns within a strip of the tile
+    const uint32_t ep_rboff = (uint32_t)(wm * 128 + l15) * 2u;           // MODE 3 (row bias): this lane's row within the tile, m tile 0
     // GATE: the output is [M, N / 2]; a wave's 128 tile columns = two gated strips of 32 columns = one 128-byte line per row
     const int ep_gn = a.N >> 1;
     const uint32_t ep_voff_g = (uint32_t)((wm * 128 + (l15 & 7)) * ep_gn + wn * 64 + 8 * lq + 32 * (l15 >> 3)) * 2u;
@@ -729,16 +731,26 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
 #define GE_NR 6                              /* residual requests in flight (a ring of GE_NR x 4 VGPRs; 8 spills fragment registers) */
 #define GE_LOAD(U) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rr[(U) % GE_NR]) : "v"(ep_voff), "s"(rd), "s"(GE_SOFF(U)) : "memory")
             g_u32x4 rr[GE_NR], bq[4], ost[8], o_even;
-            if (BIAS) {                                          // the lane's eight columns of every strip
+            uint32_t rbq[8];                                     // MODE 3: the bias of this lane's row in each of the eight m tiles
+            if (BIAS && MODE != 3) {                             // the lane's eight columns of every strip
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[b]) : "v"(ep_boff), "s"(a.bias + n0 + b * 32) : "memory");
+            }
+            if (BIAS && MODE == 3) {
+                // swapped operands: the rows of this launch are the dense layer's OUTPUT FEATURES, so the bias runs along m -- one
+                // bf16 per lane and m tile (row m0 + wm 128 + 16 j + l15), the same value for the lane's eight columns
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    asm volatile("global_load_ushort %0, %1, %2" : "=v"(rbq[j]) : "v"(ep_rboff), "s"(a.bias + m0 + 16 * j) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rbq[0]), "+v"(rbq[1]), "+v"(rbq[2]), "+v"(rbq[3]), "+v"(rbq[4]), "+v"(rbq[5]),
+                             "+v"(rbq[6]), "+v"(rbq[7]) :: "memory");
             }
             if (RES) {                                           // residual rows: a ring of eight requests ahead of the arithmetic
 #pragma unroll
                 for (int u = 0; u < GE_NR; ++u) GE_LOAD(u);
             }
-            if (BIAS && !RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
+            if (BIAS && !RES && MODE != 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
 #pragma unroll
             for (int u = 0; u < 32; ++u) {                       // unit (b, j): n tiles 2 b, 2 b + 1 x m tile j = 16 rows x 64 B
                 const int b = GE_B(u), j = GE_J(u);
@@ -760,9 +772,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                 // the next tile's zeros, here: the epilogue runs at the pace of its stores (~270 cycles per store instruction and
                 // wave, whatever it carries), the eight writes are free; behind the loop they cost 1.4 k cycles per tile
                 GR_ZERO1(2 * b, j); GR_ZERO1(2 * b + 1, j);
-                if (BIAS) {
+                if (BIAS && MODE != 3) {
                     v[0] += bf_lo(bq[b][0]); v[1] += bf_hi(bq[b][0]); v[2] += bf_lo(bq[b][1]); v[3] += bf_hi(bq[b][1]);
                     v[4] += bf_lo(bq[b][2]); v[5] += bf_hi(bq[b][2]); v[6] += bf_lo(bq[b][3]); v[7] += bf_hi(bq[b][3]);
+                }
+                if (BIAS && MODE == 3) {
+                    const float rb = bf_lo(rbq[j]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rb;
                 }
                 if (RES) {
                     const g_u32x4 r = rr[u % GE_NR];
@@ -954,3 +971,34 @@ extern "C" int evo_linear_zg_mfma_bf16(const void* x, const void* w, const void*
     return evo_launch_status();
 }
 
+
+// z^T [N][Mp] = (x [Mp, K] . w [N, K]^T + bias [N])^T: the Hyena projection with a CHANNEL-MAJOR result for csrc/hyena_ct.hip --
+// [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections].  The persistent kernel is launched with its operands
+// SWAPPED (its "X" = w: the rows of the result are output features; its "W" = x: the columns are tokens), so a lane's eight
+// consecutive output columns are eight consecutive TOKENS of one feature and the epilogue stores whole 128-byte lines of z^T as it
+// does for y; the bias is indexed by row (MODE 3).  Bit-identical to evo_linear_mfma_bf16's result, transposed (same k order of
+// the same products, one rounding).  Mp % 256 == 0 (the caller pads: every row of x is computed), N % 256 == 0, K % 64 == 0, K >= 128.
+extern "C" int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N, int64_t K,
+                                      void* stream) {
+    if (Mp <= 0 || N <= 0 || K <= 0 || Mp % GBN != 0 || N % GBM != 0 || K % GBK != 0 || K < 2 * GBK || Mp > 0x7fffffff / 2) return -1;
+    if (Mp * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
+    GemmArgs a;
+    a.x = (const unsigned char*)w; a.w = (const unsigned char*)x; a.bias = (const uint16_t*)bias; a.res = nullptr; a.y = (uint16_t*)zt;
+    a.M = N; a.N = (int)Mp; a.K = (int)K; a.Mtot = N;
+    a.tiles_n = (int)(Mp / GBN);
+    a.tiles_m = (int)(N / GBM);
+    static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    a.group_m = group_env >= 1 ? group_env : (a.tiles_n >= 32 ? 8 : 4);
+    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+    if (tiles > 0x7fffffff) return -1;
+    a.n_tiles = (int)tiles;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        n &= ~7;
+        return n < 8 ? 8 : n;
+    }();
+    if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 3>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 3>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+    return evo_launch_status();
+}

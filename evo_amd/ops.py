@@ -39,6 +39,9 @@ _SIGNATURES = {
     "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 8 + [_PTR], _c.c_int),
+    "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 10 + [_PTR], _c.c_int),
+    "evo_linear_t_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _PTR], _c.c_int),
     "evo_linear_xblk_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -53,7 +56,7 @@ _SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 6          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 7          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -180,6 +183,10 @@ class HipOps:
         self.hyena_mfma = True          # the single-pass matrix-core operator (False: the modal three-launch kernels; tests' yardstick)
         # ... on group-major z by the channel-stationary kernel (csrc/hyena_cs.hip, round 4) with a blocked y; False: the round-3 kernel
         self.hyena_cs_flag = True
+        # ... or on CHANNEL-MAJOR z^T (csrc/hyena_ct.hip: the projection launched with swapped operands, no input window in LDS);
+        # False: group-major z and hyena_cs.hip
+        self.hyena_ct_flag = True
+        self._xpad = {}                 # zero-initialised padded inputs of the swapped-operand projection, by (rows, D, device)
         self.last_hyena_io = {}
 
     def _t(self, name):
@@ -336,6 +343,105 @@ class HipOps:
             _check(self.lib.evo_rmsnorm_bf16(x.data_ptr(), _ptr(bias), scale.data_ptr(), out.data_ptr(), M, D,
                                              float(eps), _stream()), "evo_rmsnorm_bf16")
         return out
+
+    # ---- the channel-major (z^T) form of the Hyena block's input: csrc/hyena_ct.hip -------------------------------------------
+    @staticmethod
+    def zt_geometry(B: int, T: int):
+        """(Tp, Mp): batch rows at a pitch of Tp = T rounded up to 8 positions (16-byte loads of eight steps), Mp = B Tp rounded up
+        to the dense layer's 256-row tile.  A pure function of the sizes."""
+        Tp = (T + 7) // 8 * 8
+        return Tp, (B * Tp + 255) // 256 * 256
+
+    def zt_shape_ok(self, B: int, T: int, N: int, K: int) -> bool:
+        Tp, Mp = self.zt_geometry(B, T)
+        return (self.hyena_ct_flag and B * T >= 256 and N % 256 == 0 and N % 384 == 0 and K % 64 == 0 and K >= 128
+                and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mp * 2 < 0xfffffff0 and Mp <= 0x7fffffff // 2)
+
+    def rmsnorm_rows(self, x: torch.Tensor, scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
+        """RMSNorm of x [B T, D] written with padded batch rows: -> [Mp, D] (zt_geometry), row b T + t at b Tp + t.  The buffer is
+        a cached workspace per shape (the pad rows are zero and never written), valid until the next call with the same shape."""
+        self._need(x, torch.bfloat16, "rmsnorm x")
+        self._need(scale, torch.bfloat16, "rmsnorm scale")
+        M, D = x.shape
+        assert M == B * T
+        Tp, Mp = self.zt_geometry(B, T)
+        key = (Mp, D, x.device)
+        out = self._xpad.get(key)
+        if out is None:
+            self._xpad.clear()                               # (one shape at a time: a scoring run keeps its shape)
+            out = self._xpad[key] = torch.zeros(Mp, D, dtype=torch.bfloat16, device=x.device)
+        with self._t("rmsnorm"):
+            _check(self.lib.evo_rmsnorm_rows_bf16(x.data_ptr(), None, scale.data_ptr(), out.data_ptr(), M, D, float(eps), T, Tp,
+                                                  _stream()), "evo_rmsnorm_rows_bf16")
+        return out
+
+    def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """z^T [N, Mp] bf16 = (xp [Mp, K] @ w [N, K]^T + b)^T: the dense layer launched with swapped operands (csrc/gemm.hip, mode 3);
+        w in the REFERENCE's row order (no regrouped copy)."""
+        self._need(xp, torch.bfloat16, "linear_t x")
+        self._need(w, torch.bfloat16, "linear_t w")
+        Mp, K = xp.shape
+        N = w.shape[0]
+        zt = torch.empty(N, Mp, dtype=torch.bfloat16, device=xp.device)
+        with self._t("gemm_zt"):
+            _check(self.lib.evo_linear_t_mfma_bf16(xp.data_ptr(), w.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K, _stream()),
+                   "evo_linear_t_mfma_bf16")
+        return zt
+
+    @staticmethod
+    def zt_rows(zt: torch.Tensor, B: int, T: int, t0: int, n: int) -> torch.Tensor:
+        """Steps t0 .. t0 + n - 1 of every batch row of a channel-major z^T [3 D, Mp] as token-major [B, n, 3 D] (reference column order)."""
+        Tp = (T + 7) // 8 * 8
+        return zt[:, :B * Tp].view(zt.shape[0], B, Tp)[:, :, t0:t0 + n].permute(1, 2, 0).contiguous()
+
+    def hyena_ct(self, zt, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
+                 state_only=False, b_first=0, y_blk=None, y_row0=0):
+        """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [3 D, Mp] bf16 =
+        linear_t's result on rmsnorm_rows' padded rows; B batch rows of T tokens starting at batch row `b_first` of the tensor
+        (a sub-range: the row groups of a sequence-parallel shard).  Arguments and results as hyena_cs; `z_halo` [B, 2, 3 D] in
+        the REFERENCE's column order."""
+        self._need(zt, torch.bfloat16, "hyena z^T")
+        D3, Mp = zt.shape
+        D = D3 // 3
+        Tp = (T + 7) // 8 * 8
+        assert D3 == 3 * D and (b_first + B) * Tp <= Mp
+        if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
+            raise RuntimeError("hyena_ct: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
+        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b")):
+            self._need(t, torch.bfloat16, "hyena " + nm)
+        if z_halo is not None:
+            self._need(z_halo, torch.bfloat16, "hyena z_halo")
+            assert z_halo.shape == (B, 2, 3 * D)
+        s0r = None
+        if s0 is not None:
+            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
+            assert s0r.shape == (B, D, 8, 2) and s0r.is_cuda
+        s_fin = None
+        if want_state or state_only:
+            if poles is None:
+                raise RuntimeError("hyena_ct: the end state needs the poles")
+            self._need(poles, torch.float32, "hyena poles")
+            assert tuple(poles.shape) == (D, 8, 2)
+            s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=zt.device)
+        yb_rows = 0
+        if state_only:
+            y = None
+        elif y_blk is not None:
+            self._need(y_blk, torch.bfloat16, "hyena y (blocked)")
+            assert y_blk.dim() == 4 and tuple(y_blk.shape[1:]) == (D // 16, self.YBLK, 16)
+            yb_rows = y_blk.shape[0] * self.YBLK
+            assert 0 <= y_row0 and y_row0 + B * T <= yb_rows
+            y = y_blk
+        else:
+            y = torch.empty(B, T, D, dtype=torch.bfloat16, device=zt.device)
+        with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
+            _check(self.lib.evo_hyena_ct(zt.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(), _ptr(y),
+                                         _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, Mp, Tp, b_first * Tp,
+                                         1 if state_only else 0, yb_rows, y_row0, _stream()), "evo_hyena_ct")
+        if state_only:
+            return torch.view_as_complex(s_fin)
+        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}
+        return (y, torch.view_as_complex(s_fin)) if want_state else y
 
     def hyena_prefill(self, z: torch.Tensor, fir_w: torch.Tensor, fir_b: torch.Tensor, poles: torch.Tensor,
                       residues: torch.Tensor, dskip: torch.Tensor, n_heads: int,

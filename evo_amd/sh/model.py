@@ -210,11 +210,13 @@ class StripedHyena(nn.Module):
                 f._fir_w = f.short_filter_weight.data.reshape(3 * D, self.short_filter_length).contiguous()
                 f._poles = f.poles.data.reshape(D, self.state_size, 2).float().contiguous()
                 f._residues = f.residues.data.reshape(D, self.state_size, 2).float().contiguous()
-                # grouped projection + operand table of the matrix-core operator: a row-permuted copy of the projection weight (100 MB
-                # per layer at D = 4096) and the [D,52,64] operand table (54 MB) -- 4.5 GB for the 29 Hyena layers of the 7B model,
-                # beside the 12.9 GB of weights; built by _mfma_pack on the first parallel Hyena call of the layer
-                # (every bench / test does untimed warm-up passes first), never for decode-only use
+                # the [D,52,64] operand table of the matrix-core operator (54 MB per layer, 1.6 GB for the 29 Hyena layers of the 7B
+                # model): built by _mfma_table on the first parallel Hyena call of the layer (every bench / test does untimed warm-up
+                # passes first), never for decode-only use.  The row-permuted copy of the projection weight (100 MB per layer) is
+                # built only where the GROUP-MAJOR path runs (_mfma_pack: sequence-parallel shards, shapes outside the z^T contract);
+                # the channel-major path of round 4 reads the projection weight as it is.
                 f._mfma = None
+                f._mfma_tab = None
         self._packed = True
 
     # ------------------------------------------------------------------ caches
@@ -331,18 +333,32 @@ class StripedHyena(nn.Module):
         split = min(B, (256 + groups - 1) // groups)
         return T >= 32 and B * T >= 256 and B * T * D * 2 < 0xfffffff0 and (groups * split) % 8 == 0
 
+    def _mfma_table(self, blk):
+        """The MFMA operand table of a Hyena block's filter (evo_amd/hyena_tables.py), built on first use."""
+        f = blk.filter
+        if getattr(f, "_mfma_tab", None) is None or f._mfma_tab.device != blk.projections.weight.device:
+            from ..hyena_tables import mfma_operand_table
+            f._mfma_tab = mfma_operand_table(f._poles, f._residues, f.D.data)
+        return f._mfma_tab
+
     def _mfma_pack(self, blk):
-        """(grouped projection weight, grouped bias, MFMA operand table, perm, inverse perm) of a Hyena block."""
+        """(grouped projection weight, grouped bias, MFMA operand table, perm, inverse perm) of a Hyena block -- the group-major
+        path's pack (the channel-major path of hyena_ct.hip reads the projection weight as it is: _mfma_table alone)."""
         f = blk.filter
         if getattr(f, "_mfma", None) is None or f._mfma[0].device != blk.projections.weight.device:
-            from ..hyena_tables import group_permutation, mfma_operand_table
+            from ..hyena_tables import group_permutation
             w, b = blk.projections.weight.data, blk.projections.bias
             perm = group_permutation(self.hidden_size, self.num_heads, w.device)
             inv = torch.empty_like(perm)
             inv[perm] = torch.arange(perm.numel(), device=perm.device)
-            table = mfma_operand_table(f._poles, f._residues, f.D.data)
-            f._mfma = (w[perm].contiguous(), None if b is None else b.data[perm].contiguous(), table, perm, inv)
+            f._mfma = (w[perm].contiguous(), None if b is None else b.data[perm].contiguous(), self._mfma_table(blk), perm, inv)
         return f._mfma
+
+    def _hyena_ct_ok(self, x2d, blk, B, T) -> bool:
+        ops = self.ops
+        w = blk.projections.weight
+        return (getattr(ops, "hyena_ct_flag", False) and hasattr(ops, "hyena_ct") and x2d.is_cuda and w.dtype == torch.bfloat16
+                and w.is_contiguous() and ops.zt_shape_ok(B, T, w.shape[0], w.shape[1]))
 
     def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams], mask=None):
         """`mask` = (flat [B*T,1] bf16, [B,T] uint8) of upstream's padding_mask, or None: the projections output, the FIR
@@ -362,6 +378,28 @@ class StripedHyena(nn.Module):
             # prefill too (carry-in state + FIR history in, end state out).  It wants the projection's output columns grouped
             # [16-channel group][x2 | x1 | v]: the projection GEMM writes that layout directly from a row-permuted copy of
             # its weight (built once per layer, with the layer's MFMA operand table).
+            if self._hyena_ct_ok(x2d, blk, B, T):
+                # round 4, second form: z CHANNEL-MAJOR.  The pre-norm writes its rows with every batch row padded to a multiple of
+                # 8 positions, the projection's dense layer runs with swapped operands (result = z^T, the weight as it is -- no
+                # regrouped copy) and the operator loads a lane's eight steps of a channel as 16 contiguous bytes straight into
+                # registers (csrc/hyena_ct.hip: no window in LDS); y BLOCKED as below.  Scoring and cached prefill alike.
+                table = self._mfma_table(blk)
+                xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
+                zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data)
+                yb = ops.yblk_empty(B * T, D, zt.device)
+                if cache is None:
+                    y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)
+                else:
+                    halo = s0 = None
+                    if have_state:              # continue a cached prefix with more than one token
+                        halo = cache.fir_state_dict[i].transpose(1, 2).contiguous()
+                        s0 = cache.state_dict[i]
+                    y, state = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
+                                            want_state=True, poles=f._poles, y_blk=yb)
+                    cache.fir_state_dict[i] = ops.zt_rows(zt, B, T, T - K1, K1).transpose(1, 2).contiguous()   # [B, 3D, 2]
+                    cache.state_dict[i] = state
+                self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias), None)
+                return
             wg, bg, table, perm, inv = self._mfma_pack(blk)
             if cache is None:
                 n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)

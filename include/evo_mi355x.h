@@ -32,8 +32,10 @@ extern "C" {
  *   5: evo_mlp_gate_mfma_bf16 (GELU * gate in the dense layer's epilogue), evo_linear_zg_mfma_bf16 (group-major result) and
  *      evo_hyena_mfma_zg (the single-pass operator on group-major z) added.
  *   6: evo_hyena_cs_zg (the single-pass operator with channel-stationary waves: outputs, end state or state-only walk; blocked y)
- *      and evo_linear_xblk_mfma_bf16 (the output projection on that blocked y) added. */
-#define EVO_ABI_VERSION 6
+ *      and evo_linear_xblk_mfma_bf16 (the output projection on that blocked y) added.
+ *   7: evo_hyena_ct (the same operator on channel-major z^T: no input window in LDS), evo_linear_t_mfma_bf16 (the projection with
+ *      a transposed result) and evo_rmsnorm_rows_bf16 (RMSNorm with padded batch rows) added. */
+#define EVO_ABI_VERSION 7
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -151,6 +153,29 @@ int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const 
  * layer of evo_linear_mfma_bf16 with other source addresses for its X tiles; M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128. */
 int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
                               int64_t M, int64_t N, int64_t K, void* stream);
+
+/* The same operator once more -- same reference steps, same arithmetic, same y / state forms as evo_hyena_cs_zg -- on CHANNEL-MAJOR
+ * z (csrc/hyena_ct.hip, round 4): zt [3 D][zt_pitch] bf16 is the projection's result TRANSPOSED (row = column c = h*3*hd + g*hd + j
+ * of z in the reference's order, no regrouping; written by evo_linear_t_mfma_bf16); batch row b, token t sits at position
+ * zt_row0 + b * row_pitch + t of every row.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into
+ * the registers the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0, zt_pitch % 8 == 0
+ * (16-byte loads), zt 16-byte aligned; positions between T and row_pitch may hold anything.  z_halo [B, 2, 3 D] bf16 in the
+ * REFERENCE's column order (rows = steps -2, -1) or NULL. */
+int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
+                 const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
+                 int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t state_only, int64_t y_blocked_rows,
+                 int64_t y_row0, void* stream);
+
+/* The Hyena projection with a transposed result              [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections]:
+ * zt [N][Mp] bf16 = (x [Mp, K] . w [N, K]^T + bias [N])^T -- the persistent dense layer of evo_linear_mfma_bf16 launched with its
+ * operands swapped (rows of the result = output features, columns = tokens; the bias runs along the rows), bit-identical to that
+ * layer's result, transposed.  Mp % 256 == 0 (the caller pads x: see evo_rmsnorm_rows_bf16), N % 256 == 0, K % 64 == 0, K >= 128. */
+int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N, int64_t K, void* stream);
+
+/* evo_rmsnorm_bf16 with the output rows of every batch row of T tokens at a pitch of Tp >= T rows: row b * T + t of x [M = B T, D]
+ * -> row b * Tp + t of out [>= B Tp, D]; the pad rows are not written.  Same arithmetic, same bits per row. */
+int evo_rmsnorm_rows_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps,
+                          int64_t T, int64_t Tp, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
  * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]

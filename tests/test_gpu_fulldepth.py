@@ -173,7 +173,7 @@ def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
     assert err <= floor                                       # never further from fp32 than eager bf16 is
 
 
-@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "round3_hyena"])
+@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "group_major_hyena", "round3_hyena"])
 def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     """(b) BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
     oracle run on that prefix alone (the model is causal) -- end to end, and block by block with the engine's own
@@ -182,16 +182,18 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     with a group-major result, the Hyena output projections gathering the operator's blocked y, the gated MLP's first half with
     GELU * gate in the epilogue -- launch counts asserted: zero library GEMMs), and the three in-process A/B routings bench.py
     times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt), `unfused` (dense layer +
-    gate kernel) and `round3_hyena` (ops.hyena_cs_flag = False: csrc/hyena_mfma.hip, row-major y)."""
+    gate kernel), `group_major_hyena` (ops.hyena_ct_flag = False: csrc/hyena_cs.hip on group-major z, the first form of this round)
+    and `round3_hyena` (also ops.hyena_cs_flag = False: csrc/hyena_mfma.hip, row-major y)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P, row = 2049, 3
     ids = acgt_ids(8, 8192)
     m = full["m8"]
     ops = m.ops
-    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag
+    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag, ops.hyena_ct_flag
     ops.all_gemm_mfma = gemm != "library_l3"
     ops.mlp_gate_fused = gemm != "unfused"
     ops.hyena_cs_flag = gemm != "round3_hyena"
+    ops.hyena_ct_flag = gemm not in ("round3_hyena", "group_major_hyena")
     if ops.timer is None:
         from evo_amd.ops import KernelTimer
         ops.timer = KernelTimer()
@@ -204,12 +206,13 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
         launches = {k_: n for k_, (n, _) in ops.timer.summary().items()}
     finally:
         m.block_taps = None
-        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag = was
+        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag, ops.hyena_ct_flag = was
         ops.timer = None
     # the routing under test really ran (here `model(ids)` materialises logits through ops.linear: one more dense layer than a
     # scoring step, whose unembedding is fused into the tail kernel)
     print(f"[prefix {gemm}] launches: {launches}")
-    assert launches.get("gemm_zg", 0) == 29 and launches.get("hyena_mfma", 0) == 29
+    proj = "gemm_zt" if ops.hyena_ct_flag and gemm not in ("round3_hyena", "group_major_hyena") else "gemm_zg"
+    assert launches.get(proj, 0) == 29 and launches.get("hyena_mfma", 0) == 29 and launches.get("gemm_zg" if proj == "gemm_zt" else "gemm_zt", 0) == 0
     if gemm == "library_l3":
         assert launches.get("gemm", 0) >= 32 and launches.get("gemm_gate", 0) == 32
     elif gemm == "unfused":

@@ -594,3 +594,141 @@ def test_hyena_cs_is_bit_reproducible_at_bench_size(ops):
     e = (ys[0].double() - ref.double()).abs()
     assert float(e.norm() / ref.double().norm()) < 3e-4
     assert (e <= ref.double().abs() * 2.0 ** -7 + float(ref.abs().max()) * 1e-3).all()
+
+
+# ---- round 4, second form: the channel-stationary operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip) ----------------------------------
+def _zt_of(ops, z, B, T, pad_value=float("nan")):
+    """z [B, T, 3 D] -> z^T [3 D, Mp] as rmsnorm_rows + linear_t lay it out (batch rows at a pitch of Tp); the pad positions hold
+    `pad_value` (NaN by default: whatever sits there must never reach an output or the state)."""
+    Tp, Mp = ops.zt_geometry(B, T)
+    zt = torch.full((z.shape[-1], Mp), pad_value, dtype=torch.bfloat16, device=z.device)
+    zt[:, :B * Tp].view(-1, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
+    return zt
+
+
+@pytest.mark.parametrize("B,T,D,H", [
+    (2, 37, 128, 1),             # one ragged tile
+    (1, 1, 128, 1),              # single token
+    (2, 513, 256, 2),            # a full tile + 1 step: the tile-to-tile carry, lane 0's history from lane 63 of the previous tile
+    (1, 513, 4096, 32),          # BASELINE configs[0] length at the real width
+    (2, 8193, 256, 2),           # BASELINE configs[1] length: 17 tiles, batch rows padded 8,193 -> 8,200
+    (1, 3000, 128, 1),
+    (40, 300, 128, 1),           # more batch rows than row streams: workgroups walk several rows (history re-seeded per row)
+    (3, 1100, 256, 2),           # the pipeline crosses a row boundary mid-stream
+    (8, 2049, 1024, 8),
+    (9, 1024, 256, 2),           # T a multiple of the tile: no ragged tile, no padding
+])
+def test_hyena_ct_matches_oracle_and_the_group_major_kernel(ops, B, T, D, H):
+    """evo_hyena_ct (z^T in, a lane's eight steps loaded as 16 contiguous bytes, no window in LDS) vs the fp64 oracle -- outputs and
+    end state, with and without FIR history and a carry-in state, the state-only walk, row-major and blocked y -- and vs
+    evo_hyena_cs_zg on the same numbers in group-major order: the same arithmetic term for term (asserted to bf16-rounding
+    boundaries; bit equality is reported)."""
+    from evo_amd.hyena_tables import mfma_operand_table, group_permutation
+    prm = hyena_params(D, 100)
+    fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(101))).to(DEV)
+    halo = bf(torch.randn(B, 2, 3 * D, generator=gen(102))).to(DEV)
+    s0 = torch.view_as_complex(torch.randn(B, D, 8, 2, generator=gen(103)).contiguous()).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    perm = group_permutation(D, H, DEV)
+    hg = halo[..., perm].contiguous()
+    zg = z[..., perm].contiguous().view(B * T, D // 16, 48).transpose(0, 1).contiguous()
+    zt = _zt_of(ops, z, B, T)
+    for kw in (dict(), dict(z_halo=halo), dict(z_halo=halo, s0=s0)):
+        y_new, s_new = ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles, **kw)
+        assert not bool(torch.isnan(y_new.float()).any()) and not bool(torch.isnan(torch.view_as_real(s_new)).any())
+        y_pln = ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, **kw)                     # the scoring instantiation (no end state)
+        assert torch.equal(y_pln, y_new), list(kw)
+        yb = ops.yblk_empty(B * T + 77, D, DEV).fill_(7.0)
+        ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=yb, y_row0=77, **kw)
+        rows = ops.yblk_to_rows(yb, B * T + 77)
+        assert torch.equal(rows[77:].view(B, T, D), y_new), list(kw)
+        assert bool((rows[:77] == 7.0).all())                                          # nothing written in front of y_row0
+        s_only = ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, poles=poles, state_only=True, **kw)
+        assert torch.equal(torch.view_as_real(s_only), torch.view_as_real(s_new)), list(kw)
+        ry, rst = R.op_hyena(z.cpu(), *prm, H, **{k: (halo if k == "z_halo" else s0).cpu() for k in kw})
+        assert_close_bf16(y_new, ry, rl2=2e-3 if y_new.numel() > 4096 else 3.5e-3)
+        assert (s_new.cpu().to(torch.complex128) - rst).abs().max() <= 2e-5 * rst.abs().max(), list(kw)
+        kg = {k: (hg if k == "z_halo" else v) for k, v in kw.items()}
+        y_cs, s_cs = ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles, **kg)
+        d = (y_new.double() - y_cs.double()).abs()
+        print(f"[hyena_ct vs hyena_cs {B}x{T}x{D} {list(kw)}] outputs differing: {int((d > 0).sum())} of {d.numel()}, "
+              f"state max diff {(s_new - s_cs).abs().max().item():.2e}")
+        assert (d <= y_cs.double().abs() * 2.0 ** -7 + 1e-4 * float(y_cs.abs().max())).all(), list(kw)
+        assert float((d > 0).double().mean()) < 0.02, (list(kw), float((d > 0).double().mean()))
+        assert (s_new - s_cs).abs().max().item() <= 2e-6 * s_cs.abs().max().item()
+
+
+def test_hyena_ct_pad_positions_do_not_matter(ops):
+    """What sits between T and the row pitch (and behind the last row) never reaches an output: NaN, zeros and large finite values there
+    give the same bits."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    B, T, D, H = 5, 1003, 256, 2
+    prm = hyena_params(D, 120)
+    fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(121))).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    outs = [ops.hyena_ct(_zt_of(ops, z, B, T, v), B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles) for v in (float("nan"), 0.0, 3e38)]
+    for y, s in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(torch.view_as_real(s), torch.view_as_real(outs[0][1]))
+
+
+def test_hyena_ct_row_subrange(ops):
+    """`b_first`: the row groups of a sequence-parallel shard are launched on sub-ranges of the batch rows of ONE z^T tensor."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    B, T, D, H = 5, 700, 256, 2
+    prm = hyena_params(D, 110)
+    fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(111))).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    zt = _zt_of(ops, z, B, T)
+    y_all = ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H)
+    assert torch.equal(ops.hyena_ct(zt, 2, T, fir_w, fir_b, tab, H, b_first=3), y_all[3:5])
+    assert torch.equal(ops.hyena_ct(_zt_of(ops, z[1:4].contiguous(), 3, T), 3, T, fir_w, fir_b, tab, H), y_all[1:4])
+    assert torch.equal(ops.zt_rows(zt, B, T, T - 2, 2), z[:, T - 2:])
+
+
+@pytest.mark.parametrize("B,T,D", [(3, 1003, 256), (1, 2500, 512), (8, 8193, 256), (2, 640, 4096)])
+def test_rmsnorm_rows_and_transposed_projection_are_bitwise_the_plain_ones(ops, B, T, D):
+    """rmsnorm_rows + linear_t (the dense layer with swapped operands, bias along the rows) = rmsnorm + the plain hand-written dense
+    layer, transposed and with the batch rows at a pitch of Tp: bit for bit."""
+    x = bf(torch.randn(B * T, D, generator=gen(130))).to(DEV)
+    scale = bf(1.0 + 0.1 * torch.randn(D, generator=gen(131))).to(DEV)
+    w = bf(torch.randn(3 * D, D, generator=gen(132)) * D ** -0.5).to(DEV)
+    b = bf(torch.randn(3 * D, generator=gen(133)) * 0.1).to(DEV)
+    Tp, Mp = ops.zt_geometry(B, T)
+    assert Tp % 8 == 0 and Tp >= T and Tp - T < 8 and Mp % 256 == 0 and Mp >= B * Tp and ops.zt_shape_ok(B, T, 3 * D, D)
+    n_ref = ops.rmsnorm(x, None, scale, 1e-6)
+    xp = ops.rmsnorm_rows(x, scale, 1e-6, B, T)
+    assert tuple(xp.shape) == (Mp, D)
+    assert torch.equal(xp[:B * Tp].view(B, Tp, D)[:, :T].reshape(B * T, D), n_ref)
+    assert bool((xp[:B * Tp].view(B, Tp, D)[:, T:] == 0).all()) and bool((xp[B * Tp:] == 0).all())
+    for bias in (b, None):
+        zt = ops.linear_t(xp, w, bias)
+        M256 = B * T // 256 * 256
+        z_ref = ops.linear_mfma(n_ref[:M256].contiguous(), w, bias)                     # [M256, 3 D] on the same kernel, plain orientation
+        got = ops.zt_rows(zt, B, T, 0, T).reshape(B * T, 3 * D)[:M256]
+        assert torch.equal(got, z_ref), int((got != z_ref).sum())
+        z_all = torch.nn.functional.linear(n_ref.float(), w.float(), None if bias is None else bias.float())
+        err = (ops.zt_rows(zt, B, T, 0, T).reshape(B * T, 3 * D).float() - z_all).abs().max().item()
+        assert err <= 2.0 ** -7 * z_all.abs().max().item(), err
+
+
+def test_hyena_ct_is_bit_reproducible_at_bench_size(ops):
+    """8 x 8,193 x 4096 (BASELINE configs[1]): eight launches on the same data are bit-identical and agree with the three-launch
+    modal path to one bf16 rounding."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    B, T, D, H = 8, 8193, 4096, 32
+    prm = [t.to(DEV) for t in hyena_params(D, 64)]
+    fir_w, fir_b, poles, res, dskip = prm
+    z = bf(torch.randn(B, T, 3 * D, generator=gen(65))).to(DEV)
+    tab = mfma_operand_table(poles, res, dskip)
+    zt = _zt_of(ops, z, B, T)
+    ys = [ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H).clone() for _ in range(8)]
+    for k in range(1, 8):
+        assert torch.equal(ys[k], ys[0]), k
+    ref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    e = (ys[0].double() - ref.double()).abs()
+    assert float(e.norm() / ref.double().norm()) < 3e-4
+    assert (e <= ref.double().abs() * 2.0 ** -7 + float(ref.abs().max()) * 1e-3).all()

@@ -184,3 +184,53 @@ def test_blocked_y_layout_and_the_dense_layers_gather():
     z2 = torch.zeros_like(zg)
     HipOps.zg_set_rows(z2, B, T, 0, zt)
     assert torch.equal(z2, zg)
+
+
+def test_ct_lane_positions_history_lanes_and_zt_geometry():
+    """csrc/hyena_ct.hip: the index arithmetic of the channel-major form, replayed on the host.  Lane (la = lane & 15, lq = lane >> 4)
+    of a tile loads the eight positions row0 + b Tp + 512 tile + 32 la + 8 lq .. + 7 of a column of z^T (16 bytes); the two steps
+    before them are the last pair of lane `hist_src` (lane - 16, or lane + 47 for lq = 0), for lane 0 the last pair of lane 63 of
+    the previous tile, at the start of a row the halo / zeros.  Reassembling every channel's stream from these pieces must give
+    back the sequence, for ragged T, rows padded to Tp and several batch rows."""
+    import torch
+    from evo_amd.ops import HipOps
+    for (B, T) in ((3, 1100), (2, 513), (1, 37), (4, 1024)):
+        Tp, Mp = HipOps.zt_geometry(B, T)
+        assert Tp % 8 == 0 and 0 <= Tp - T < 8 and Mp % 256 == 0 and Mp >= B * Tp
+        z = torch.arange(1, B * T + 1, dtype=torch.float32).view(B, T)            # one column: value = 1 + flat index (0 = "nothing")
+        col = torch.full((Mp,), -1.0)                                              # pad positions: a value that must never be used
+        col[:B * Tp].view(B, Tp)[:, :T] = z
+        pos_max = Mp - 8
+        n_tiles = (T + 511) // 512
+        for b in range(B):
+            carry = None
+            for tile in range(n_tiles):
+                rw = {}
+                for lane in range(64):
+                    la, lq = lane & 15, lane >> 4
+                    p = min(b * Tp + tile * 512 + 32 * la + 8 * lq, pos_max)
+                    rw[lane] = col[p:p + 8]
+                for lane in range(64):
+                    la, lq = lane & 15, lane >> 4
+                    t0 = tile * 512 + 32 * la + 8 * lq
+                    if lane == 0:
+                        hist = torch.zeros(2) if tile == 0 else carry
+                    else:
+                        src = lane - 16 if lq > 0 else lane + 47
+                        hist = rw[src][6:8]
+                    for i in range(-2, 8):
+                        t = t0 + i
+                        if t >= T or t0 >= T:
+                            continue                                               # masked steps (n_valid): whatever was loaded
+                        got = (hist[i + 2] if i < 0 else rw[lane][i]).item()
+                        want = z[b, t].item() if t >= 0 else 0.0
+                        assert got == want, (B, T, b, tile, lane, i)
+                carry = rw[63][6:8]
+    # zt_rows: token-major rows out of z^T
+    B, T, C = 3, 13, 6
+    Tp, Mp = HipOps.zt_geometry(B, T)
+    zz = torch.randn(B, T, C)
+    zt = torch.zeros(C, Mp)
+    zt[:, :B * Tp].view(C, B, Tp)[:, :, :T] = zz.permute(2, 0, 1)
+    assert torch.equal(HipOps.zt_rows(zt, B, T, T - 2, 2), zz[:, T - 2:])
+    assert torch.equal(HipOps.zt_rows(zt, B, T, 0, T), zz)

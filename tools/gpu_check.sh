@@ -22,18 +22,18 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof131 -o p -- python $R/tools/profile_131k.py > $R/$O/prof_131k.log 2>&1
 cd $R && python tools/summarize_prof.py stats $O/prof131 > $O/bench_131k_kernel_stats.txt && rm -rf $O/prof131
 head -14 $O/bench_131k_kernel_stats.txt
-# HBM-side traffic of the Hyena operator as the scoring path launches it (hyena_cs: group-major z, blocked y): separate counter
+# HBM-side traffic of the Hyena operator as the scoring path launches it (hyena_ct: channel-major z^T, blocked y): separate counter
 # passes (no trace domains beside --kernel-trace)
 cd /tmp
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zrd -o r -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zrd.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zwr -o w -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zwr.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_cs" > $O/hyena_cs_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
+cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_c[st]" > $O/hyena_cs_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
 cat $O/hyena_cs_pmc_traffic.txt
 # SQ counters of the same launches (instruction mix, LDS activity / bank conflicts, wait states)
 cd /tmp
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq1 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq2 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq2.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_cs" > $O/hyena_cs_sq_counters.txt; rm -rf $O/sq1 $O/sq2
+cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_c[st]" > $O/hyena_cs_sq_counters.txt; rm -rf $O/sq1 $O/sq2
 cat $O/hyena_cs_sq_counters.txt | cut -c1-200
 # the same for a decode run (BASELINE configs[4] shape: 8,192-nt prompt, greedy): per-kernel times of the generation leg
 cd /tmp

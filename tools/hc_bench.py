@@ -2,8 +2,9 @@
 """A/B timing of single-pass Hyena kernels on GROUP-MAJOR z (HIP events on the launch stream), D = 4096, H = 32, at the two bench
 shapes (8 x 8,193 and 1 x 131,073 tokens).
     python tools/hc_bench.py libevo_mi355x.so old:libevo_mi355x.so libevo_hc_nw4.so
-Each argument is a file in evo_amd/_lib/: plain = its evo_hyena_cs_zg (csrc/hyena_cs.hip, round 4) with the BLOCKED y output (what the
-model runs), prefix `rm:` = the same with row-major y, prefix `old:` = its evo_hyena_mfma_zg (csrc/hyena_mfma.hip, round 3).  Every build is checked against the three-launch modal operator of the default
+Each argument is a file in evo_amd/_lib/: prefix `ct:` = its evo_hyena_ct (csrc/hyena_ct.hip: channel-major z^T, blocked y -- what the model
+runs), plain = its evo_hyena_cs_zg (csrc/hyena_cs.hip, group-major z) with the BLOCKED y output, prefix `rm:` = the same with row-major y,
+prefix `old:` = its evo_hyena_mfma_zg (csrc/hyena_mfma.hip, round 3).  Every build is checked against the three-launch modal operator of the default
 library on the same data (and for bit-reproducibility) before it is timed.  Timing as in a scoring step: every launch follows the
 projection's dense layer that writes its z (evo_linear_zg_mfma_bf16 of the default library); events bracket the Hyena launch only;
 the builds are interleaved round by round in ONE process (boxes differ by 25 % in clock)."""
@@ -27,12 +28,15 @@ perm = group_permutation(D, H, dev)
 P = ctypes.c_void_p; I = ctypes.c_int64
 libs = []
 for arg in sys.argv[1:]:
-    old = "old" if arg.startswith("old:") else ("rm" if arg.startswith("rm:") else "")
+    old = "old" if arg.startswith("old:") else ("rm" if arg.startswith("rm:") else ("ct" if arg.startswith("ct:") else ""))
     name = arg.split(":", 1)[1] if old else arg
     lib = ctypes.CDLL(str(_build.LIBDIR / name))
     if old == "old":
         fn = lib.evo_hyena_mfma_zg
         fn.argtypes = [P] * 10 + [I] * 4 + [P]
+    elif old == "ct":
+        fn = lib.evo_hyena_ct
+        fn.argtypes = [P] * 9 + [I] * 10 + [P]
     else:
         fn = lib.evo_hyena_cs_zg
         fn.argtypes = [P] * 9 + [I] * 8 + [P]
@@ -45,6 +49,9 @@ for (B, T) in shapes:
     z = rn(B, T, 3 * D).bfloat16()
     ref, sref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, want_state=True)
     zg = z[..., perm].view(B * T, D // 16, 48).transpose(0, 1).contiguous()          # [groups, B T, 48]
+    Tp, Mp = ops.zt_geometry(B, T)
+    zt = torch.zeros(3 * D, Mp, dtype=torch.bfloat16, device=dev)                    # [3 D, Mp]: batch rows at a pitch of Tp
+    zt[:, :B * Tp].view(3 * D, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
     nbytes = B * T * D * 8
     y = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
     yb = ops.yblk_empty(B * T, D, dev)
@@ -55,6 +62,9 @@ for (B, T) in shapes:
         if old == "old":
             rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(), tab.data_ptr(), y.data_ptr(), None, so,
                     poles.data_ptr(), B, T, D, H, st)
+        elif old == "ct":
+            rc = fn(zt.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), yb.data_ptr(), None, so, poles.data_ptr(),
+                    B, T, D, H, Mp, Tp, 0, 0, yb.shape[0] * 128, 0, st)
         elif old == "rm":
             rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), y.data_ptr(), None, so, poles.data_ptr(),
                     B, T, D, H, B * T, 0, 0, 0, st)
@@ -67,7 +77,7 @@ for (B, T) in shapes:
         y.zero_()
         launch(fn, old, True)
         torch.cuda.synchronize()
-        if old == "":
+        if old in ("", "ct"):
             y.copy_(ops.yblk_to_rows(yb, B * T).view(B, T, D))
         rl2 = float((y.double() - ref.double()).norm() / ref.double().norm())
         worst = float(((y.double() - ref.double()).abs() - ref.double().abs() * 2.0 ** -7).max() / ref.abs().max())
@@ -77,7 +87,7 @@ for (B, T) in shapes:
         for _ in range(3):
             launch(fn, old)
             torch.cuda.synchronize()
-            if old == "":
+            if old in ("", "ct"):
                 y.copy_(ops.yblk_to_rows(yb, B * T).view(B, T, D))
             same = same and bool(torch.equal(y, y1))
         info[name] = (rl2, worst, srel, same)
@@ -85,13 +95,28 @@ for (B, T) in shapes:
               f"bit-reproducible {same}", flush=True)
     xin = rn(B * T, D, std=1.0).bfloat16()
     wg = rn(3 * D, D, std=0.02).bfloat16()
+    xpad = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
+    xpad[:B * Tp].view(B, Tp, D)[:, :T] = xin.view(B, T, D)
+    for nm, call in (("group-major projection (mode 2)", lambda: ops.lib.evo_linear_zg_mfma_bf16(xin.data_ptr(), wg.data_ptr(), None, zg.data_ptr(), (B * T) // 256 * 256, B * T, 3 * D, D, st)),
+                     ("transposed projection (swapped operands)", lambda: ops.lib.evo_linear_t_mfma_bf16(xpad.data_ptr(), wg.data_ptr(), None, zt.data_ptr(), Mp, 3 * D, D, st))):
+        for _ in range(2):
+            call()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(6):
+            assert call() == 0
+        b_.record(); torch.cuda.synchronize()
+        print(f"{B}x{T} {nm}: {a_.elapsed_time(b_) / 6:.4f} ms", flush=True)
     times = {name: [] for name, _, _ in libs}
     Mfull = (B * T) // 256 * 256
     for r in range(rounds + 1):
         for (name, fn, old) in libs:
             evs = []
             for _ in range(batch):
-                rc = ops.lib.evo_linear_zg_mfma_bf16(xin.data_ptr(), wg.data_ptr(), None, zg.data_ptr(), Mfull, B * T, 3 * D, D, st)
+                if old == "ct":          # (its own projection launch in front: the dense layer with swapped operands)
+                    rc = ops.lib.evo_linear_t_mfma_bf16(xpad.data_ptr(), wg.data_ptr(), None, zt.data_ptr(), Mp, 3 * D, D, st)
+                else:
+                    rc = ops.lib.evo_linear_zg_mfma_bf16(xin.data_ptr(), wg.data_ptr(), None, zg.data_ptr(), Mfull, B * T, 3 * D, D, st)
                 assert rc == 0
                 a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a_.record(); launch(fn, old); b_.record()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The single-pass Hyena operator as the scoring path launches it (csrc/hyena_cs.hip: group-major z in, blocked y out) alone, for
+"""The single-pass Hyena operator as the scoring path launches it (csrc/hyena_ct.hip: channel-major z^T in, blocked y out) alone, for
 rocprofv3 --pmc passes: 3 launches at 8 x 8,193 x 4096, then 3 at 1 x 131,073 x 4096."""
 import math, os, sys
 import torch
@@ -16,8 +16,9 @@ poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().co
 res = (rn(D, 8, 2, std=0.25) * torch.sqrt(om).unsqueeze(-1) * 4).float().contiguous()
 dskip = rn(D, std=0.5).bfloat16(); tab = mfma_operand_table(poles, res, dskip)
 for (B, T) in ((8, 8193), (1, 131073)):
-    zg = rn(D // 16, B * T, 48).bfloat16()
+    Tp, Mp = ops.zt_geometry(B, T)
+    zt = rn(3 * D, Mp).bfloat16()
     for _ in range(3):
-        ops.hyena_cs(zg, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
+        ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
     torch.cuda.synchronize()
 print("done")
