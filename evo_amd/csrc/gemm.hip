@@ -379,6 +379,20 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     }
     if (n_my == 0) return;
     auto tile_origin = [&](int tile, int64_t& m0, int& n0) {
+        if constexpr (MODE == 3) {
+            // swapped operands: the rows (m) are the WEIGHT, the columns (n) the tokens -- the raster is mirrored too, groups of
+            // group_m COLUMN tiles swept over all row tiles, so that the operand re-streamed once per group is again the weight
+            // (100 MB: it stays in the 256 MB memory-side cache) and not the activations (0.5-1 GB).  With the m-grouped raster
+            // this launch ran 4-5 % behind the group-major projection of the same shape (tools/hc_bench.py).
+            const int per_group = a.group_m * a.tiles_m;
+            const int grp = tile / per_group, in_grp = tile - grp * per_group;
+            const int first_n = grp * a.group_m;
+            const int gsz = a.tiles_n - first_n < a.group_m ? a.tiles_n - first_n : a.group_m;
+            const int tm = in_grp / gsz;
+            m0 = (int64_t)tm * GBM;
+            n0 = (first_n + in_grp - tm * gsz) * GBN;
+            return;
+        }
         const int per_group = a.group_m * a.tiles_n;
         const int grp = tile / per_group, in_grp = tile - grp * per_group;
         const int first_m = grp * a.group_m;
@@ -472,10 +486,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     }
 
     // epilogue: this lane's byte offset inside an output tile's row block (row wm 128 + l15, column wn 128 + 8 lq); 16 rows further
-    const uint32_t ep_voff = (uint32_t)((wm * 128 + l15) * a.N + wn * 128 + 8 * lq) * 2u;
-    const int ep_rows16 = 16 * a.N * 2;
+    // (MODE 3 writes its result in column blocks of 256: [N / 256][M][256] -- an output tile is ONE contiguous 128 KiB piece; as a
+    //  plain [M][N] matrix the 256 rows of a tile of z^T lie N * 2 = 130-260 KB apart, 17-33 different 2 MiB pages per tile, and the
+    //  launch ran 3-4 % behind the group-major projection at 131 k)
+    const int ldy = MODE == 3 ? GBN : a.N;
+    const uint32_t ep_voff = (uint32_t)((wm * 128 + l15) * ldy + wn * 128 + 8 * lq) * 2u;
+    const int ep_rows16 = 16 * ldy * 2;
     // whole-line form: row (l15 & 7) of an 8-row group, byte 64 (l15 >> 3) + 16 lq of the 128-byte line of a strip pair
-    const uint32_t ep_voff_f = (uint32_t)((wm * 128 + (l15 & 7)) * a.N + wn * 128 + 8 * lq + 32 * (l15 >> 3)) * 2u;
+    const uint32_t ep_voff_f = (uint32_t)((wm * 128 + (l15 & 7)) * ldy + wn * 128 + 8 * lq + 32 * (l15 >> 3)) * 2u;
     const uint32_t ep_boff = (uint32_t)(wn * 128 + 8 * lq) * 2u;        // bias: this lane's eight columns within a strip of the tile
     const uint32_t ep_rboff = (uint32_t)(wm * 128 + l15) * 2u;           // MODE 3 (row bias): this lane's row within the tile, m tile 0
     // GATE: the output is [M, N / 2]; a wave's 128 tile columns = two gated strips of 32 columns = one 128-byte line per row
@@ -724,10 +742,11 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                 GR_STAMP(8);
             } else {
             const int rows_ok = a.M - m0 < GBM ? (int)(a.M - m0) : GBM;
-            const uint64_t y64 = (uint64_t)(a.y + m0 * a.N), r64 = (uint64_t)((RES ? a.res : a.y) + m0 * a.N);
-            const g_u32x4 yd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)(rows_ok * a.N * 2), 0x00020000u};
+            const uint64_t y64 = (uint64_t)(MODE == 3 ? a.y + ((int64_t)(n0 / GBN) * a.M + m0) * GBN : a.y + m0 * a.N);
+            const uint64_t r64 = (uint64_t)((RES ? a.res : a.y) + m0 * a.N);
+            const g_u32x4 yd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)(rows_ok * ldy * 2), 0x00020000u};
             const g_u32x4 rd = {(uint32_t)r64, (uint32_t)(r64 >> 32) & 0xffffu, RES ? (uint32_t)(rows_ok * a.N * 2) : 0u, 0x00020000u};
-#define GE_SOFF(U) (n0 * 2 + 64 * GE_B(U) + GE_J(U) * ep_rows16)
+#define GE_SOFF(U) ((MODE == 3 ? 0 : n0 * 2) + 64 * GE_B(U) + GE_J(U) * ep_rows16)
 #define GE_NR 6                              /* residual requests in flight (a ring of GE_NR x 4 VGPRs; 8 spills fragment registers) */
 #define GE_LOAD(U) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rr[(U) % GE_NR]) : "v"(ep_voff), "s"(rd), "s"(GE_SOFF(U)) : "memory")
             g_u32x4 rr[GE_NR], bq[4], ost[8], o_even;
@@ -972,7 +991,8 @@ extern "C" int evo_linear_zg_mfma_bf16(const void* x, const void* w, const void*
 }
 
 
-// z^T [N][Mp] = (x [Mp, K] . w [N, K]^T + bias [N])^T: the Hyena projection with a CHANNEL-MAJOR result for csrc/hyena_ct.hip --
+// z^T = (x [Mp, K] . w [N, K]^T + bias [N])^T, stored in blocks of 256 positions, zt [Mp / 256][N][256] (element (feature c, position p) at
+// ((p / 256) * N + c) * 256 + p % 256): the Hyena projection with a CHANNEL-MAJOR result for csrc/hyena_ct.hip --
 // [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections].  The persistent kernel is launched with its operands
 // SWAPPED (its "X" = w: the rows of the result are output features; its "W" = x: the columns are tokens), so a lane's eight
 // consecutive output columns are eight consecutive TOKENS of one feature and the epilogue stores whole 128-byte lines of z^T as it
@@ -988,7 +1008,7 @@ extern "C" int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* 
     a.tiles_n = (int)(Mp / GBN);
     a.tiles_m = (int)(N / GBM);
     static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-    a.group_m = group_env >= 1 ? group_env : (a.tiles_n >= 32 ? 8 : 4);
+    a.group_m = group_env >= 1 ? group_env : (a.tiles_m >= 32 ? 8 : 4);      // (column tiles per raster group: see tile_origin, MODE 3)
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
     if (tiles > 0x7fffffff) return -1;
     a.n_tiles = (int)tiles;

@@ -7,8 +7,9 @@
 // DMA'd into LDS, published by a barrier and read back as 30 ds_read_b64 per wave and tile -- a column read of 8 bytes out of
 // 16-byte DMA granules, 2-way bank-conflicted by construction, half of every read unused (profiles/r04_hyena_cs_notes.txt: window
 // reads 1.5-2.4 k and DMA waits 0.6-0.7 k of the 7.7 k clocks a tile takes; SQ_LDS_BANK_CONFLICT 60 % of the LDS-active cycles).
-// Here z arrives TRANSPOSED, z^T [3 D columns][time]: the projection's dense layer is launched with its operands swapped
-// (evo_linear_t_mfma_bf16, csrc/gemm.hip: out[n][m] = W . x^T, the same kernel, whole-line stores), so a lane's eight steps of one
+// Here z arrives TRANSPOSED, z^T [3 D columns][time] (stored in blocks of 256 positions): the projection's dense layer is launched
+// with its operands swapped (evo_linear_t_mfma_bf16, csrc/gemm.hip: out[n][m] = W . x^T, the same kernel, whole-line stores, an
+// output tile = one contiguous 128 KiB block), so a lane's eight steps of one
 // channel and signal are 16 consecutive bytes: one global_load_dwordx4 straight into the registers the FIR reads, a wave's load =
 // 1 KiB contiguous.  No window, no DMA descriptor, no wait for other waves' pieces; the two steps of FIR history come from the
 // neighbouring lane (ds_bpermute) or, for lane 0, from lane 63 of the previous tile (v_readlane).  LDS carries only the staged bf16
@@ -43,6 +44,7 @@
 #ifndef HT_PROFILE
 #define HT_PROFILE 0
 #endif
+#define HT_ZBLK 256                         // positions per block of z^T: [position block][3 D][256]
 #define HT_YBLK 128                         // rows per block of the BLOCKED y layout: [row block][group][128 rows][16 channels]
 #define HT_TABW 52                          // dwords per lane of a channel's operand table (evo_amd/hyena_tables.py)
 #define HT_NTB 32                           // of which in registers: T0 [mt 2][hi, lo][4] = 0..15, W [hi, mid][4] = 16..23, G [mt 2][4] = 24..31
@@ -66,7 +68,7 @@ struct HtArgs {
     const unsigned char* zt; const uint16_t* z_halo; const uint16_t* fir_w; const uint16_t* fir_b;
     const uint32_t* tab; unsigned char* y; const float* s0; float* s_out; const float* poles;
     int B; int T; int D; int n_tiles; int n_groups; int nb_split;
-    int64_t zt_pitch;                                       // positions (elements) per column of z^T
+    int64_t zt_pitch;                                       // positions z^T holds per column (% 256 == 0: whole blocks)
     int64_t row_pitch;                                      // positions between two batch rows (>= T, % 8 == 0)
     int64_t zt_row0;                                        // position of batch row 0, step 0 (% 8 == 0)
     int64_t y_rowbytes;
@@ -154,12 +156,15 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int cc = 0; cc < HT_CPW; ++cc) zs[g][cc] = a.zt + (int64_t)(h * 384 + g * 128 + cw0 + ch0 + cc) * a.zt_pitch * 2;
-    const uint32_t pos_max = (uint32_t)(a.zt_pitch - 8);     // (positions past the end of a column: clamped -- they are masked steps)
+        for (int cc = 0; cc < HT_CPW; ++cc) zs[g][cc] = a.zt + (int64_t)(h * 384 + g * 128 + cw0 + ch0 + cc) * (HT_ZBLK * 2);
+    // z^T is stored in blocks of HT_ZBLK = 256 positions, [position block][3 D columns][256] (the dense layer's output tiles are then
+    // contiguous: csrc/gemm.hip, MODE 3): position p of a column sits at byte (p / 256) * 3 D * 512 + (p % 256) * 2 behind the column's base
+    const uint32_t pos_max = (uint32_t)(a.zt_pitch - 8);     // (positions past the end: clamped -- they are masked steps)
+    const uint32_t blk_bytes = (uint32_t)a.D * 3u * (HT_ZBLK * 2);
     auto voff_of = [&](const Cur& c) -> uint32_t {
         const int64_t p = a.zt_row0 + (int64_t)c.b * a.row_pitch + (int64_t)c.tile * HT_TT + 32 * la + 8 * lq;
         const uint32_t pc = p < (int64_t)pos_max ? (uint32_t)p : pos_max;
-        return pc * 2u;
+        return (pc / HT_ZBLK) * blk_bytes + (pc % HT_ZBLK) * 2u;
     };
     ht_u32x4 rw[3][HT_CPW];                                  // the tile's raw bf16 pairs: steps (0,1) (2,3) (4,5) (6,7) of this lane
     uint32_t carry_h[3][HT_CPW];                             // lane 63's last pair of the previous tile (wave-uniform)
@@ -216,6 +221,15 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v.sdat[hs]), "v"(off), "s"(ysrd) : "memory");
     };
 
+#if HT_PROFILE      // -DHT_PROFILE=1: every wave accumulates shader-clock deltas per phase and writes 16 floats at y + 64 B * (HT_NW * workgroup + wave)
+    //                 (tools/ht_stage_profile.py; a timing build: it overwrites y).  Phases: 0 wait for the tile's loads (+ the loop-carried
+    //                 copies), 1 barrier, 5 staged outputs + history, 2 FIR, 3 matrix cores + scan + stores, 4 gate + stage
+    uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
+#define HT_STAMP(K) { const uint64_t now_ = __builtin_readcyclecounter(); tprof[K] += now_ - tlast; tlast = now_; }
+#else
+#define HT_STAMP(K)
+#endif
     // ---- one tile of this wave's channels, from rw (this tile's steps) and hist (the two steps before them)
     auto compute = [&](const Cur& c, int buf, const Vm& vm, const uint32_t (&hist)[3][HT_CPW], auto ragged_t) {
         constexpr bool RAGGED = decltype(ragged_t)::value;
@@ -304,6 +318,7 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
             }
         }
 
+        HT_STAMP(2);
         // ---- per channel: E = W . X and y0 = T0 . X on the matrix cores, the block scan, y += G . S
         ht_f32x4 yv[HT_CPW][2];
 #pragma unroll
@@ -434,6 +449,7 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
             vm_store(vm, cc);                                // (tile k - 1, staged before the barrier; one 16-byte store per lane)
 #undef HT_FRAG
         }
+        HT_STAMP(3);
         // ---- gate and stage: accumulator (mt, r) of a lane is its step 4 mt + r; one dword (the wave's two channels) per step
         if (!SO) {
             unsigned char* sp = smem + stg_wr + buf * HT_STGB;
@@ -445,13 +461,6 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
 
     // ---- the pipeline: one barrier per tile (staging only).  VM queue of a wave per interval, in issue order: the loads of tile
     //      k + 1 (6; 4 in the state-only walk), then the HT_NST stores of tile k - 1.
-#if HT_PROFILE      // -DHT_PROFILE=1: every wave accumulates shader-clock deltas per phase and writes 16 floats at y + 64 B * (HT_NW * workgroup + wave)
-    uint64_t tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
-#define HT_STAMP(K) { const uint64_t now_ = __builtin_readcyclecounter(); tprof[K] += now_ - tlast; tlast = now_; }
-#else
-#define HT_STAMP(K)
-#endif
     Cur c_cmp = {b0, 0}, c_st = {b0, 0};
     if (n_steps > 0) {
         const uint32_t v0 = voff_of(c_cmp);
@@ -531,8 +540,8 @@ extern "C" int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_
     if (B * T * yrb >= 0xfffffff0ll) return -1;                                      // 32-bit offsets inside y
     if (y_blocked_rows && (y_row0 < 0 || y_row0 + B * T > y_blocked_rows || (y_blocked_rows + HT_YBLK) * yrb >= 0xfffffff0ll)) return -1;
     // z^T: 16-byte loads -> every batch row starts at a multiple of 8 positions; 32-bit byte offsets inside a column
-    if (row_pitch < T || row_pitch % 8 != 0 || zt_row0 < 0 || zt_row0 % 8 != 0 || zt_pitch % 8 != 0 || zt_pitch < 8) return -1;
-    if (zt_row0 + (B - 1) * row_pitch + T > zt_pitch || zt_pitch * 2 >= 0xfffffff0ll) return -1;
+    if (row_pitch < T || row_pitch % 8 != 0 || zt_row0 < 0 || zt_row0 % 8 != 0 || zt_pitch % HT_ZBLK != 0 || zt_pitch < HT_ZBLK) return -1;
+    if (zt_row0 + (B - 1) * row_pitch + T > zt_pitch || zt_pitch * 3 * D * 2 >= 0xfffffff0ll) return -1;   // 32-bit byte offsets inside z^T
     if (((uintptr_t)zt & 15) != 0) return -1;
     if (s_out && !poles) return -1;
     if (state_only ? !s_out : !y) return -1;

@@ -345,17 +345,20 @@ class HipOps:
         return out
 
     # ---- the channel-major (z^T) form of the Hyena block's input: csrc/hyena_ct.hip -------------------------------------------
+    ZT_ALIGN = 64       # positions a batch row of z^T is padded to (% 8 == 0: 16-byte loads; 64 = whole cache lines -- tools/hc_bench.py A/B)
+
     @staticmethod
     def zt_geometry(B: int, T: int):
-        """(Tp, Mp): batch rows at a pitch of Tp = T rounded up to 8 positions (16-byte loads of eight steps), Mp = B Tp rounded up
-        to the dense layer's 256-row tile.  A pure function of the sizes."""
-        Tp = (T + 7) // 8 * 8
+        """(Tp, Mp): batch rows at a pitch of Tp = T rounded up to ZT_ALIGN positions (16-byte loads of eight steps), Mp = B Tp
+        rounded up to the dense layer's 256-row tile.  A pure function of the sizes."""
+        al = HipOps.ZT_ALIGN
+        Tp = (T + al - 1) // al * al
         return Tp, (B * Tp + 255) // 256 * 256
 
     def zt_shape_ok(self, B: int, T: int, N: int, K: int) -> bool:
         Tp, Mp = self.zt_geometry(B, T)
         return (self.hyena_ct_flag and B * T >= 256 and N % 256 == 0 and N % 384 == 0 and K % 64 == 0 and K >= 128
-                and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mp * 2 < 0xfffffff0 and Mp <= 0x7fffffff // 2)
+                and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mp * N * 2 < 0xfffffff0)
 
     def rmsnorm_rows(self, x: torch.Tensor, scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
         """RMSNorm of x [B T, D] written with padded batch rows: -> [Mp, D] (zt_geometry), row b T + t at b Tp + t.  The buffer is
@@ -376,13 +379,13 @@ class HipOps:
         return out
 
     def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """z^T [N, Mp] bf16 = (xp [Mp, K] @ w [N, K]^T + b)^T: the dense layer launched with swapped operands (csrc/gemm.hip, mode 3);
-        w in the REFERENCE's row order (no regrouped copy)."""
+        """z^T = (xp [Mp, K] @ w [N, K]^T + b)^T in blocks of 256 positions, [Mp / 256, N, 256] bf16: the dense layer launched with
+        swapped operands (csrc/gemm.hip, mode 3); w in the REFERENCE's row order (no regrouped copy)."""
         self._need(xp, torch.bfloat16, "linear_t x")
         self._need(w, torch.bfloat16, "linear_t w")
         Mp, K = xp.shape
         N = w.shape[0]
-        zt = torch.empty(N, Mp, dtype=torch.bfloat16, device=xp.device)
+        zt = torch.empty(Mp // 256, N, 256, dtype=torch.bfloat16, device=xp.device)
         with self._t("gemm_zt"):
             _check(self.lib.evo_linear_t_mfma_bf16(xp.data_ptr(), w.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K, _stream()),
                    "evo_linear_t_mfma_bf16")
@@ -390,20 +393,32 @@ class HipOps:
 
     @staticmethod
     def zt_rows(zt: torch.Tensor, B: int, T: int, t0: int, n: int) -> torch.Tensor:
-        """Steps t0 .. t0 + n - 1 of every batch row of a channel-major z^T [3 D, Mp] as token-major [B, n, 3 D] (reference column order)."""
-        Tp = (T + 7) // 8 * 8
-        return zt[:, :B * Tp].view(zt.shape[0], B, Tp)[:, :, t0:t0 + n].permute(1, 2, 0).contiguous()
+        """Steps t0 .. t0 + n - 1 of every batch row of a channel-major z^T [Mp / 256, 3 D, 256] as token-major [B, n, 3 D] (reference
+        column order)."""
+        Tp = HipOps.zt_geometry(B, T)[0]
+        pos = (torch.arange(B, device=zt.device)[:, None] * Tp + torch.arange(t0, t0 + n, device=zt.device)[None, :]).reshape(-1)
+        return zt[pos // 256, :, pos % 256].view(B, n, zt.shape[1])
+
+    @staticmethod
+    def zt_from_rows(z: torch.Tensor, B: int, T: int, pad_value: float = 0.0) -> torch.Tensor:
+        """The inverse for whole sequences (tests, tools): token-major z [B, T, C] -> z^T [Mp / 256, C, 256], pad positions = pad_value."""
+        Tp, Mp = HipOps.zt_geometry(B, T)
+        C = z.shape[-1]
+        flat = torch.full((C, Mp), pad_value, dtype=z.dtype, device=z.device)
+        flat[:, :B * Tp].view(C, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
+        return flat.view(C, Mp // 256, 256).permute(1, 0, 2).contiguous()
 
     def hyena_ct(self, zt, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
                  state_only=False, b_first=0, y_blk=None, y_row0=0):
-        """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [3 D, Mp] bf16 =
+        """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [Mp / 256, 3 D, 256] bf16 =
         linear_t's result on rmsnorm_rows' padded rows; B batch rows of T tokens starting at batch row `b_first` of the tensor
         (a sub-range: the row groups of a sequence-parallel shard).  Arguments and results as hyena_cs; `z_halo` [B, 2, 3 D] in
         the REFERENCE's column order."""
         self._need(zt, torch.bfloat16, "hyena z^T")
-        D3, Mp = zt.shape
+        assert zt.dim() == 3 and zt.shape[2] == 256
+        D3, Mp = zt.shape[1], zt.shape[0] * 256
         D = D3 // 3
-        Tp = (T + 7) // 8 * 8
+        Tp = self.zt_geometry(B, T)[0]
         assert D3 == 3 * D and (b_first + B) * Tp <= Mp
         if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
             raise RuntimeError("hyena_ct: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")

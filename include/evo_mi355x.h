@@ -155,20 +155,22 @@ int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias
                               int64_t M, int64_t N, int64_t K, void* stream);
 
 /* The same operator once more -- same reference steps, same arithmetic, same y / state forms as evo_hyena_cs_zg -- on CHANNEL-MAJOR
- * z (csrc/hyena_ct.hip, round 4): zt [3 D][zt_pitch] bf16 is the projection's result TRANSPOSED (row = column c = h*3*hd + g*hd + j
- * of z in the reference's order, no regrouping; written by evo_linear_t_mfma_bf16); batch row b, token t sits at position
- * zt_row0 + b * row_pitch + t of every row.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into
- * the registers the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0, zt_pitch % 8 == 0
- * (16-byte loads), zt 16-byte aligned; positions between T and row_pitch may hold anything.  z_halo [B, 2, 3 D] bf16 in the
- * REFERENCE's column order (rows = steps -2, -1) or NULL. */
+ * z (csrc/hyena_ct.hip, round 4): zt [zt_pitch / 256][3 D][256] bf16 is the projection's result TRANSPOSED and stored in blocks of
+ * 256 positions -- column c = h*3*hd + g*hd + j of z (the reference's order, no regrouping), position p at element
+ * ((p / 256) * 3 D + c) * 256 + p % 256; written by evo_linear_t_mfma_bf16.  Batch row b, token t sits at position
+ * zt_row0 + b * row_pitch + t.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into the registers
+ * the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0 (16-byte loads),
+ * zt_pitch % 256 == 0, zt_pitch * 3 D * 2 < 4 GiB, zt 16-byte aligned; positions between T and row_pitch may hold anything.
+ * z_halo [B, 2, 3 D] bf16 in the REFERENCE's column order (rows = steps -2, -1) or NULL. */
 int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                  const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
                  int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t state_only, int64_t y_blocked_rows,
                  int64_t y_row0, void* stream);
 
 /* The Hyena projection with a transposed result              [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections]:
- * zt [N][Mp] bf16 = (x [Mp, K] . w [N, K]^T + bias [N])^T -- the persistent dense layer of evo_linear_mfma_bf16 launched with its
- * operands swapped (rows of the result = output features, columns = tokens; the bias runs along the rows), bit-identical to that
+ * zt [Mp / 256][N][256] bf16 = (x [Mp, K] . w [N, K]^T + bias [N])^T in blocks of 256 positions (an output tile of the kernel = one
+ * contiguous 128 KiB piece) -- the persistent dense layer of evo_linear_mfma_bf16 launched with its operands swapped (rows of the
+ * result = output features, columns = tokens; the bias runs along the rows; the tile raster mirrored), bit-identical to that
  * layer's result, transposed.  Mp % 256 == 0 (the caller pads x: see evo_rmsnorm_rows_bf16), N % 256 == 0, K % 64 == 0, K >= 128. */
 int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N, int64_t K, void* stream);
 

@@ -598,12 +598,9 @@ def test_hyena_cs_is_bit_reproducible_at_bench_size(ops):
 
 # ---- round 4, second form: the channel-stationary operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip) ----------------------------------
 def _zt_of(ops, z, B, T, pad_value=float("nan")):
-    """z [B, T, 3 D] -> z^T [3 D, Mp] as rmsnorm_rows + linear_t lay it out (batch rows at a pitch of Tp); the pad positions hold
+    """z [B, T, 3 D] -> z^T [Mp / 256, 3 D, 256] as rmsnorm_rows + linear_t lay it out (batch rows at a pitch of Tp); the pad positions hold
     `pad_value` (NaN by default: whatever sits there must never reach an output or the state)."""
-    Tp, Mp = ops.zt_geometry(B, T)
-    zt = torch.full((z.shape[-1], Mp), pad_value, dtype=torch.bfloat16, device=z.device)
-    zt[:, :B * Tp].view(-1, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
-    return zt
+    return ops.zt_from_rows(z, B, T, pad_value)
 
 
 @pytest.mark.parametrize("B,T,D,H", [
@@ -697,7 +694,7 @@ def test_rmsnorm_rows_and_transposed_projection_are_bitwise_the_plain_ones(ops, 
     w = bf(torch.randn(3 * D, D, generator=gen(132)) * D ** -0.5).to(DEV)
     b = bf(torch.randn(3 * D, generator=gen(133)) * 0.1).to(DEV)
     Tp, Mp = ops.zt_geometry(B, T)
-    assert Tp % 8 == 0 and Tp >= T and Tp - T < 8 and Mp % 256 == 0 and Mp >= B * Tp and ops.zt_shape_ok(B, T, 3 * D, D)
+    assert Tp % 8 == 0 and Tp >= T and Tp - T < ops.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp and ops.zt_shape_ok(B, T, 3 * D, D)
     n_ref = ops.rmsnorm(x, None, scale, 1e-6)
     xp = ops.rmsnorm_rows(x, scale, 1e-6, B, T)
     assert tuple(xp.shape) == (Mp, D)
@@ -705,6 +702,7 @@ def test_rmsnorm_rows_and_transposed_projection_are_bitwise_the_plain_ones(ops, 
     assert bool((xp[:B * Tp].view(B, Tp, D)[:, T:] == 0).all()) and bool((xp[B * Tp:] == 0).all())
     for bias in (b, None):
         zt = ops.linear_t(xp, w, bias)
+        assert tuple(zt.shape) == (Mp // 256, 3 * D, 256)
         M256 = B * T // 256 * 256
         z_ref = ops.linear_mfma(n_ref[:M256].contiguous(), w, bias)                     # [M256, 3 D] on the same kernel, plain orientation
         got = ops.zt_rows(zt, B, T, 0, T).reshape(B * T, 3 * D)[:M256]

@@ -196,7 +196,7 @@ def test_ct_lane_positions_history_lanes_and_zt_geometry():
     from evo_amd.ops import HipOps
     for (B, T) in ((3, 1100), (2, 513), (1, 37), (4, 1024)):
         Tp, Mp = HipOps.zt_geometry(B, T)
-        assert Tp % 8 == 0 and 0 <= Tp - T < 8 and Mp % 256 == 0 and Mp >= B * Tp
+        assert Tp % 8 == 0 and 0 <= Tp - T < HipOps.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp
         z = torch.arange(1, B * T + 1, dtype=torch.float32).view(B, T)            # one column: value = 1 + flat index (0 = "nothing")
         col = torch.full((Mp,), -1.0)                                              # pad positions: a value that must never be used
         col[:B * Tp].view(B, Tp)[:, :T] = z
@@ -230,7 +230,15 @@ def test_ct_lane_positions_history_lanes_and_zt_geometry():
     B, T, C = 3, 13, 6
     Tp, Mp = HipOps.zt_geometry(B, T)
     zz = torch.randn(B, T, C)
-    zt = torch.zeros(C, Mp)
-    zt[:, :B * Tp].view(C, B, Tp)[:, :, :T] = zz.permute(2, 0, 1)
+    zt = HipOps.zt_from_rows(zz, B, T)
+    assert tuple(zt.shape) == (Mp // 256, C, 256)
     assert torch.equal(HipOps.zt_rows(zt, B, T, T - 2, 2), zz[:, T - 2:])
     assert torch.equal(HipOps.zt_rows(zt, B, T, 0, T), zz)
+    # the kernel's byte offset of position p of column c: (p / 256) * C * 512 + (p % 256) * 2 behind the column base c * 512
+    flat = zt.reshape(-1)
+    for b in range(B):
+        for t in (0, 5, T - 1):
+            p = b * Tp + t
+            for c in (0, C - 1):
+                off = c * 512 + (p // 256) * C * 512 + (p % 256) * 2
+                assert flat[off // 2].item() == zz[b, t, c].item()

@@ -16,6 +16,8 @@ from evo_amd.ops import default_ops
 from evo_amd.hyena_tables import mfma_operand_table, group_permutation
 
 ops = default_ops(); dev = "cuda:0"; D, H = 4096, 32
+type(ops).ZT_ALIGN = int(os.environ.get("HC_ZT_ALIGN", type(ops).ZT_ALIGN))          # batch-row pitch of z^T (A/B: 8 | 64)
+print("z^T batch rows padded to", type(ops).ZT_ALIGN, "positions", flush=True)
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s, std=1.0: torch.randn(*s, generator=g, device=dev) * std
 fir_w = rn(3 * D, 3, std=0.3).bfloat16(); fir_b = rn(3 * D, std=0.1).bfloat16()
@@ -50,8 +52,7 @@ for (B, T) in shapes:
     ref, sref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, want_state=True)
     zg = z[..., perm].view(B * T, D // 16, 48).transpose(0, 1).contiguous()          # [groups, B T, 48]
     Tp, Mp = ops.zt_geometry(B, T)
-    zt = torch.zeros(3 * D, Mp, dtype=torch.bfloat16, device=dev)                    # [3 D, Mp]: batch rows at a pitch of Tp
-    zt[:, :B * Tp].view(3 * D, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
+    zt = ops.zt_from_rows(z, B, T)                                                   # [Mp / 256, 3 D, 256]: batch rows at a pitch of Tp
     nbytes = B * T * D * 8
     y = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
     yb = ops.yblk_empty(B * T, D, dev)
