@@ -27,14 +27,14 @@ head -14 $O/bench_131k_kernel_stats.txt
 cd /tmp
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zrd -o r -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zrd.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zwr -o w -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zwr.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_c[st]" > $O/hyena_cs_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
-cat $O/hyena_cs_pmc_traffic.txt
+cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_c[st]" > $O/hyena_ct_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
+cat $O/hyena_ct_pmc_traffic.txt
 # SQ counters of the same launches (instruction mix, LDS activity / bank conflicts, wait states)
 cd /tmp
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq1 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq2 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq2.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_c[st]" > $O/hyena_cs_sq_counters.txt; rm -rf $O/sq1 $O/sq2
-cat $O/hyena_cs_sq_counters.txt | cut -c1-200
+cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_c[st]" > $O/hyena_ct_sq_counters.txt; rm -rf $O/sq1 $O/sq2
+cat $O/hyena_ct_sq_counters.txt | cut -c1-200
 # the same for a decode run (BASELINE configs[4] shape: 8,192-nt prompt, greedy): per-kernel times of the generation leg
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/profg -o g -- python $R/tools/bench_generate.py --new 128 > $R/$O/prof_gen.log 2>&1
