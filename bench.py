@@ -452,6 +452,19 @@ def main():
         "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
     }
+    # ------------------------------------------------------------------ the A/B legs' own reference: the DEFAULT routing timed exactly as the legs are
+    # (3 steps behind one warm-up, here and again behind the last leg: the headline's 5 steps were timed minutes earlier in the process and the
+    # part's clocks drift by ~1 % meanwhile -- compare a leg with `ab_reference`, not with the headline)
+    def _ab_ref():
+        with torch.inference_mode():
+            dtr = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+        return dtr / 3 * 1e3
+    if n_gpus == 1 and not args.skip_ab:
+        try:
+            out["ab_reference"] = {"ms_per_step_before_legs": _ab_ref(), "steps": 3,
+                                   "note": "the default routing (this run's headline configuration) timed the way the A/B legs are, in front of and behind them"}
+        except Exception as e:  # noqa: BLE001
+            out["ab_reference"] = {"error": f"{type(e).__name__}: {e}"}
     # ------------------------------------------------------------------ the same step with the plain dense layers on hipBLASLt
     if n_gpus == 1 and ops.all_gemm_mfma and not args.skip_ab:
         try:
@@ -521,6 +534,11 @@ def main():
             ops.timer = None
             ops.hyena_cs_flag = True
             ops.hyena_ct_flag = True
+    if n_gpus == 1 and not args.skip_ab and "ms_per_step_before_legs" in out.get("ab_reference", {}):
+        try:
+            out["ab_reference"]["ms_per_step_after_legs"] = _ab_ref()
+        except Exception as e:  # noqa: BLE001
+            out["ab_reference"]["error"] = f"{type(e).__name__}: {e}"
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         try:
