@@ -50,10 +50,16 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+__device__ __forceinline__ int64_t rms_out_row(int64_t row, int64_t T, int64_t Tp, int64_t Tm, int64_t tail0) {
+    if (T == 0) return row;
+    const int64_t b = row / T, t = row - b * T;
+    return t < Tm ? b * Tp + t : tail0 + b * (T - Tm) + (t - Tm);
+}
+
 template <bool HAS_BIAS, int NV>   // NV = register-cached 16-byte vectors per lane (row <= NV*512 elements)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
                                                       const uint4* __restrict__ scale, uint4* __restrict__ out,
-                                                      int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t pad) {
+                                                      int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t Tp, int64_t Tm, int64_t tail0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
@@ -82,8 +88,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, con
         }
         ss = wave_sum(ss);
         const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
-        // (evo_rmsnorm_rows_bf16: batch row b = row / T of the output starts at position b * (T + pad))
-        uint4* orow = out + (row + (T ? row / T * pad : 0)) * nvec;
+        // (evo_rmsnorm_rows_bf16: token t < Tm of batch row b = row / T goes to row b * Tp + t, the row's last T - Tm tokens to the
+        //  compact tail rows tail0 + b * (T - Tm) + (t - Tm))
+        uint4* orow = out + rms_out_row(row, T, Tp, Tm, tail0) * nvec;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int idx = lane + 64 * i;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint4* __restrict__ x, con
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x, const uint4* __restrict__ bias,
                                                            const uint4* __restrict__ scale, uint4* __restrict__ out,
-                                                           int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t pad) {
+                                                           int64_t M, int nvec, float eps, float inv_sqrt_d, int64_t T, int64_t Tp, int64_t Tm, int64_t tail0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x
         }
         ss = wave_sum(ss);
         const float inv = 1.0f / (sqrtf(ss) * inv_sqrt_d + eps);
-        uint4* orow = out + (row + (T ? row / T * pad : 0)) * nvec;
+        uint4* orow = out + rms_out_row(row, T, Tp, Tm, tail0) * nvec;
         for (int idx = lane; idx < nvec; idx += 64) {
             float f[8], s[8];
             unpack8(xr[idx], f);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void rmsnorm_long_kernel(uint4* __restrict__ x
 }
 
 static int rmsnorm_launch(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps, int64_t T,
-                          int64_t pad, void* stream) {
+                          int64_t Tp, int64_t Tm, int64_t tail0, void* stream) {
     if (D % 8 != 0 || D <= 0 || M < 0) return -1;
     if (M == 0) return 0;
     int nvec = (int)(D / 8);
@@ -147,7 +154,7 @@ static int rmsnorm_launch(void* x, const void* bias, const void* scale, void* ou
     hipStream_t s = (hipStream_t)stream;
 #define EVO_RMS_LAUNCH(K)                                                                                          \
     hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, s, (uint4*)x, (const uint4*)bias, (const uint4*)scale,        \
-                       (uint4*)out, M, nvec, eps, isd, T, pad)
+                       (uint4*)out, M, nvec, eps, isd, T, Tp, Tm, tail0)
     if (nvec <= 64 * 2) {
         if (bias) EVO_RMS_LAUNCH((rmsnorm_kernel<true, 2>)); else EVO_RMS_LAUNCH((rmsnorm_kernel<false, 2>));
     } else if (nvec <= 64 * 8) {
@@ -161,16 +168,16 @@ static int rmsnorm_launch(void* x, const void* bias, const void* scale, void* ou
 
 extern "C" int evo_rmsnorm_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D,
                                 float eps, void* stream) {
-    return rmsnorm_launch(x, bias, scale, out, M, D, eps, 0, 0, stream);
+    return rmsnorm_launch(x, bias, scale, out, M, D, eps, 0, 0, 0, 0, stream);
 }
 
-// The same norm with the output rows of every batch row of T tokens placed at a pitch of Tp >= T rows (out [B * Tp, D]; the pad rows
-// are not written): the input form of the swapped-operand Hyena projection, whose result z^T wants every batch row to start at a
-// multiple of 8 positions (csrc/hyena_ct.hip).  M = B * T rows of x.
+// The same norm with the output rows in the order of a channel-major z^T (HipOps.zt_layout): token t < Tm of batch row b at row
+// b * Tp + t (Tp >= Tm: the pad rows are not written), the row's last T - Tm tokens compactly at rows tail0 + b * (T - Tm) + (t - Tm) -- the
+// inputs of the swapped-operand Hyena projection (main rows) and of the weight-streaming kernel (tail rows).  M = B * T rows of x; Tm = T: no tail.
 extern "C" int evo_rmsnorm_rows_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps,
-                                     int64_t T, int64_t Tp, void* stream) {
-    if (T <= 0 || Tp < T || M % T != 0) return -1;
-    return rmsnorm_launch(x, bias, scale, out, M, D, eps, T, Tp - T, stream);
+                                     int64_t T, int64_t Tp, int64_t Tm, int64_t tail0, void* stream) {
+    if (T <= 0 || Tm <= 0 || Tm > T || Tp < Tm || M % T != 0 || (Tm < T && tail0 < M / T * Tp)) return -1;
+    return rmsnorm_launch(x, bias, scale, out, M, D, eps, T, Tp, Tm, tail0, stream);
 }
 
 // ------------------------------------------------------------------------------------------- rope

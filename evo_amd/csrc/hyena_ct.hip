@@ -71,6 +71,7 @@ struct HtArgs {
     int64_t zt_pitch;                                       // positions z^T holds per column (% 256 == 0: whole blocks)
     int64_t row_pitch;                                      // positions between two batch rows (>= T, % 8 == 0)
     int64_t zt_row0;                                        // position of batch row 0, step 0 (% 8 == 0)
+    int64_t tail_T, tail_pos0;                              // tail form (0: none): steps >= tail_T of batch row b sit at tail_pos0 + 8 b + (t - tail_T)
     int64_t y_rowbytes;
     int y_blk;                                              // y is [ceil(rows / 128)][D / 16][128][16] bf16 instead of [rows][D]
     int64_t y_row0, y_rows;                                 // blocked y: row of batch row 0 / total rows of the [rows, D] matrix it stands for
@@ -162,7 +163,11 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
     const uint32_t pos_max = (uint32_t)(a.zt_pitch - 8);     // (positions past the end: clamped -- they are masked steps)
     const uint32_t blk_bytes = (uint32_t)a.D * 3u * (HT_ZBLK * 2);
     auto voff_of = [&](const Cur& c) -> uint32_t {
-        const int64_t p = a.zt_row0 + (int64_t)c.b * a.row_pitch + (int64_t)c.tile * HT_TT + 32 * la + 8 * lq;
+        // (tail form: T = 512 k + r, r <= 8 -- the row's last r tokens came through the weight-streaming kernel into the tail block of z^T
+        //  (HipOps.zt_layout); they are the whole ragged last tile, whose lane 0 loads them; every other lane of that tile is masked)
+        const int64_t t0 = (int64_t)c.tile * HT_TT;
+        const int64_t p = (a.tail_T && t0 >= a.tail_T ? a.tail_pos0 + (int64_t)c.b * 8 + (t0 - a.tail_T)
+                                                      : a.zt_row0 + (int64_t)c.b * a.row_pitch + t0) + 32 * la + 8 * lq;
         const uint32_t pc = p < (int64_t)pos_max ? (uint32_t)p : pos_max;
         return (pc / HT_ZBLK) * blk_bytes + (pc % HT_ZBLK) * 2u;
     };
@@ -533,15 +538,19 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
 
 extern "C" int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                             const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                            int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t state_only, int64_t y_blocked_rows,
-                            int64_t y_row0, void* stream) {
+                            int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t tail_T, int64_t tail_pos0, int64_t state_only,
+                            int64_t y_blocked_rows, int64_t y_row0, void* stream) {
     if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0 || D != n_heads * 128) return -1;
     const int64_t yrb = D * 2;
     if (B * T * yrb >= 0xfffffff0ll) return -1;                                      // 32-bit offsets inside y
     if (y_blocked_rows && (y_row0 < 0 || y_row0 + B * T > y_blocked_rows || (y_blocked_rows + HT_YBLK) * yrb >= 0xfffffff0ll)) return -1;
     // z^T: 16-byte loads -> every batch row starts at a multiple of 8 positions; 32-bit byte offsets inside a column
-    if (row_pitch < T || row_pitch % 8 != 0 || zt_row0 < 0 || zt_row0 % 8 != 0 || zt_pitch % HT_ZBLK != 0 || zt_pitch < HT_ZBLK) return -1;
-    if (zt_row0 + (B - 1) * row_pitch + T > zt_pitch || zt_pitch * 3 * D * 2 >= 0xfffffff0ll) return -1;   // 32-bit byte offsets inside z^T
+    if ((!tail_T && row_pitch < T) || row_pitch % 8 != 0 || zt_row0 < 0 || zt_row0 % 8 != 0 || zt_pitch % HT_ZBLK != 0 || zt_pitch < HT_ZBLK) return -1;
+    if (zt_pitch * 3 * D * 2 >= 0xfffffff0ll) return -1;                                                    // 32-bit byte offsets inside z^T
+    if (tail_T) {            // the last T - tail_T <= 8 tokens of every row in the tail block: the whole ragged last tile
+        if (tail_T % HT_TT != 0 || T <= tail_T || T - tail_T > 8 || row_pitch < tail_T || tail_pos0 % 8 != 0) return -1;
+        if (zt_row0 + (B - 1) * row_pitch + tail_T > tail_pos0 || tail_pos0 + B * 8 > zt_pitch) return -1;
+    } else if (zt_row0 + (B - 1) * row_pitch + T > zt_pitch) return -1;
     if (((uintptr_t)zt & 15) != 0) return -1;
     if (s_out && !poles) return -1;
     if (state_only ? !s_out : !y) return -1;
@@ -555,7 +564,7 @@ extern "C" int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_
     a.zt = (const unsigned char*)zt; a.z_halo = (const uint16_t*)z_halo; a.fir_w = (const uint16_t*)fir_w; a.fir_b = (const uint16_t*)fir_b;
     a.tab = (const uint32_t*)table; a.y = (unsigned char*)y; a.s0 = s0; a.s_out = s_out; a.poles = poles;
     a.B = (int)B; a.T = (int)T; a.D = (int)D; a.n_tiles = (int)((T + HT_TT - 1) / HT_TT); a.n_groups = (int)groups;
-    a.nb_split = (int)nb_split; a.zt_pitch = zt_pitch; a.row_pitch = row_pitch; a.zt_row0 = zt_row0; a.y_rowbytes = yrb;
+    a.nb_split = (int)nb_split; a.zt_pitch = zt_pitch; a.row_pitch = row_pitch; a.zt_row0 = zt_row0; a.tail_T = tail_T; a.tail_pos0 = tail_pos0; a.y_rowbytes = yrb;
     a.y_blk = y_blocked_rows ? 1 : 0; a.y_row0 = y_row0; a.y_rows = y_blocked_rows;
     if (state_only) hipLaunchKernelGGL((hyena_ct_kernel<true, true>), dim3((unsigned)streams), dim3(HT_THREADS), 0, (hipStream_t)stream, a);
     else if (s_out) hipLaunchKernelGGL((hyena_ct_kernel<false, true>), dim3((unsigned)streams), dim3(HT_THREADS), 0, (hipStream_t)stream, a);

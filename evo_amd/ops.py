@@ -39,9 +39,9 @@ _SIGNATURES = {
     "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 8 + [_PTR], _c.c_int),
-    "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 10 + [_PTR], _c.c_int),
+    "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 12 + [_PTR], _c.c_int),
     "evo_linear_t_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _PTR], _c.c_int),
+    "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_linear_xblk_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -348,78 +348,112 @@ class HipOps:
     ZT_ALIGN = 64       # positions a batch row of z^T is padded to (% 8 == 0: 16-byte loads; 64 = whole cache lines -- tools/hc_bench.py A/B)
 
     @staticmethod
-    def zt_geometry(B: int, T: int):
-        """(Tp, Mp): batch rows at a pitch of Tp = T rounded up to ZT_ALIGN positions (16-byte loads of eight steps), Mp = B Tp
-        rounded up to the dense layer's 256-row tile.  A pure function of the sizes."""
+    def zt_layout(B: int, T: int):
+        """(Tm, Tp, Mp, r): where batch row b / token t of a [B, T] batch sits in z^T -- a pure function of the sizes.
+        Position b * Tp + t for t < Tm (the MAIN area: Mp = B Tp rounded up to the dense layer's 256-row tile positions), and for the
+        r = T - Tm last tokens of a row position Mp + 8 b + (t - Tm) (the TAIL block, one more block of 256 positions behind the main area).
+        Plain form: r = 0, Tm = T, Tp = T rounded up to ZT_ALIGN.  Tail form: T = 512 k + r with 1 <= r <= 8 (the bench shapes: a BOS token in
+        front of 2^k nucleotides) -- rows of 512 k positions need no padding and B * 512 k is a whole number of tiles, where the padded rows
+        cost the persistent dense layer one more round (+2.5 ... 4 % per projection, profiles/r04_hyena_ct_notes.txt section 3); the B r <= 16
+        tail tokens go through the weight-streaming kernel, as the BOS sliver of every other dense layer does (_tail_rows)."""
         al = HipOps.ZT_ALIGN
         Tp = (T + al - 1) // al * al
-        return Tp, (B * Tp + 255) // 256 * 256
+        Mp = (B * Tp + 255) // 256 * 256
+        r = T % 512
+        Tm = T - r
+        if 1 <= r <= 8 and Tm >= 512 and B * r <= 16 and Tm % al == 0 and (B * Tm + 255) // 256 * 256 < Mp:
+            return Tm, Tm, (B * Tm + 255) // 256 * 256, r
+        return T, Tp, Mp, 0
+
+    @staticmethod
+    def zt_geometry(B: int, T: int):
+        """(Tp, Mp) of zt_layout: the row pitch and the number of positions of the main area."""
+        _, Tp, Mp, _ = HipOps.zt_layout(B, T)
+        return Tp, Mp
+
+    @staticmethod
+    def zt_positions(B: int, T: int, b: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """Position in z^T of (batch row b, token t), elementwise (zt_layout)."""
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
+        return torch.where(t < Tm, b * Tp + t, Mp + 8 * b + (t - Tm))
 
     def zt_shape_ok(self, B: int, T: int, N: int, K: int) -> bool:
-        Tp, Mp = self.zt_geometry(B, T)
+        _, _, Mp, r = self.zt_layout(B, T)
+        P = Mp + (256 if r else 0)
         return (self.hyena_ct_flag and B * T >= 256 and N % 256 == 0 and N % 384 == 0 and K % 64 == 0 and K >= 128
-                and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mp * N * 2 < 0xfffffff0)
+                and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and P * N * 2 < 0xfffffff0)
 
     def rmsnorm_rows(self, x: torch.Tensor, scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
-        """RMSNorm of x [B T, D] written with padded batch rows: -> [Mp, D] (zt_geometry), row b T + t at b Tp + t.  The buffer is
-        a cached workspace per shape (the pad rows are zero and never written), valid until the next call with the same shape."""
+        """RMSNorm of x [B T, D] written in the row order of zt_layout: -> [Mp + 16, D], row b T + t at its z^T position for t < Tm, the
+        B r tail tokens compactly at rows Mp + b r + (t - Tm) (the weight-streaming kernel's input).  The buffer is a cached workspace per
+        shape (the pad rows are zero and never written), valid until the next call with the same shape."""
         self._need(x, torch.bfloat16, "rmsnorm x")
         self._need(scale, torch.bfloat16, "rmsnorm scale")
         M, D = x.shape
         assert M == B * T
-        Tp, Mp = self.zt_geometry(B, T)
+        Tm, Tp, Mp, r = self.zt_layout(B, T)
         key = (Mp, D, x.device)
         out = self._xpad.get(key)
         if out is None:
             self._xpad.clear()                               # (one shape at a time: a scoring run keeps its shape)
-            out = self._xpad[key] = torch.zeros(Mp, D, dtype=torch.bfloat16, device=x.device)
+            out = self._xpad[key] = torch.zeros(Mp + 16, D, dtype=torch.bfloat16, device=x.device)
         with self._t("rmsnorm"):
-            _check(self.lib.evo_rmsnorm_rows_bf16(x.data_ptr(), None, scale.data_ptr(), out.data_ptr(), M, D, float(eps), T, Tp,
+            _check(self.lib.evo_rmsnorm_rows_bf16(x.data_ptr(), None, scale.data_ptr(), out.data_ptr(), M, D, float(eps), T, Tp, Tm, Mp,
                                                   _stream()), "evo_rmsnorm_rows_bf16")
         return out
 
-    def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """z^T = (xp [Mp, K] @ w [N, K]^T + b)^T in blocks of 256 positions, [Mp / 256, N, 256] bf16: the dense layer launched with
-        swapped operands (csrc/gemm.hip, mode 3); w in the REFERENCE's row order (no regrouped copy)."""
+    def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], B: int, T: int) -> torch.Tensor:
+        """z^T = (x @ w [N, K]^T + b)^T in blocks of 256 positions, [Mp / 256 (+ 1), N, 256] bf16, from rmsnorm_rows' buffer xp: the dense
+        layer launched with swapped operands on the Mp main rows (csrc/gemm.hip, mode 3), the tail tokens (zt_layout) through the
+        weight-streaming kernel into the tail block; w in the REFERENCE's row order (no regrouped copy)."""
         self._need(xp, torch.bfloat16, "linear_t x")
         self._need(w, torch.bfloat16, "linear_t w")
-        Mp, K = xp.shape
+        Tm, Tp, Mp, r = self.zt_layout(B, T)
+        K = xp.shape[1]
         N = w.shape[0]
-        zt = torch.empty(Mp // 256, N, 256, dtype=torch.bfloat16, device=xp.device)
+        assert xp.shape[0] >= Mp + B * r
+        zt = torch.empty(Mp // 256 + (1 if r else 0), N, 256, dtype=torch.bfloat16, device=xp.device)
         with self._t("gemm_zt"):
             _check(self.lib.evo_linear_t_mfma_bf16(xp.data_ptr(), w.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K, _stream()),
                    "evo_linear_t_mfma_bf16")
+        if r:
+            z_tail = self._linear_small_m(xp[Mp:Mp + B * r], w, b, None)                # [B r, N]
+            zt[-1].view(N, 32, 8)[:, :B, :r] = z_tail.view(B, r, N).permute(2, 0, 1)      # position Mp + 8 b + j
         return zt
 
     @staticmethod
     def zt_rows(zt: torch.Tensor, B: int, T: int, t0: int, n: int) -> torch.Tensor:
-        """Steps t0 .. t0 + n - 1 of every batch row of a channel-major z^T [Mp / 256, 3 D, 256] as token-major [B, n, 3 D] (reference
+        """Steps t0 .. t0 + n - 1 of every batch row of a channel-major z^T [blocks, 3 D, 256] as token-major [B, n, 3 D] (reference
         column order)."""
-        Tp = HipOps.zt_geometry(B, T)[0]
-        pos = (torch.arange(B, device=zt.device)[:, None] * Tp + torch.arange(t0, t0 + n, device=zt.device)[None, :]).reshape(-1)
+        bb = torch.arange(B, device=zt.device)[:, None].expand(B, n)
+        tt = torch.arange(t0, t0 + n, device=zt.device)[None, :].expand(B, n)
+        pos = HipOps.zt_positions(B, T, bb, tt).reshape(-1)
         return zt[pos // 256, :, pos % 256].view(B, n, zt.shape[1])
 
     @staticmethod
     def zt_from_rows(z: torch.Tensor, B: int, T: int, pad_value: float = 0.0) -> torch.Tensor:
-        """The inverse for whole sequences (tests, tools): token-major z [B, T, C] -> z^T [Mp / 256, C, 256], pad positions = pad_value."""
-        Tp, Mp = HipOps.zt_geometry(B, T)
+        """The inverse for whole sequences (tests, tools): token-major z [B, T, C] -> z^T [blocks, C, 256], pad positions = pad_value."""
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
         C = z.shape[-1]
-        flat = torch.full((C, Mp), pad_value, dtype=z.dtype, device=z.device)
-        flat[:, :B * Tp].view(C, B, Tp)[:, :, :T] = z.permute(2, 0, 1)
-        return flat.view(C, Mp // 256, 256).permute(1, 0, 2).contiguous()
+        P = Mp + (256 if r else 0)
+        flat = torch.full((C, P), pad_value, dtype=z.dtype, device=z.device)
+        flat[:, :B * Tp].view(C, B, Tp)[:, :, :Tm] = z[:, :Tm].permute(2, 0, 1)
+        if r:
+            flat[:, Mp:].view(C, 32, 8)[:, :B, :r] = z[:, Tm:].permute(2, 0, 1)
+        return flat.view(C, P // 256, 256).permute(1, 0, 2).contiguous()
 
     def hyena_ct(self, zt, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
-                 state_only=False, b_first=0, y_blk=None, y_row0=0):
-        """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [Mp / 256, 3 D, 256] bf16 =
-        linear_t's result on rmsnorm_rows' padded rows; B batch rows of T tokens starting at batch row `b_first` of the tensor
-        (a sub-range: the row groups of a sequence-parallel shard).  Arguments and results as hyena_cs; `z_halo` [B, 2, 3 D] in
-        the REFERENCE's column order."""
+                 state_only=False, b_first=0, y_blk=None, y_row0=0, b_total=None):
+        """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [blocks, 3 D, 256] bf16 =
+        linear_t's result (zt_layout of a [b_total, T] batch; b_total defaults to b_first + B); B batch rows of T tokens starting at
+        batch row `b_first` of the tensor (a sub-range).  Arguments and results as hyena_cs; `z_halo` [B, 2, 3 D] in the REFERENCE's
+        column order."""
         self._need(zt, torch.bfloat16, "hyena z^T")
         assert zt.dim() == 3 and zt.shape[2] == 256
-        D3, Mp = zt.shape[1], zt.shape[0] * 256
+        D3, P = zt.shape[1], zt.shape[0] * 256
         D = D3 // 3
-        Tp = self.zt_geometry(B, T)[0]
-        assert D3 == 3 * D and (b_first + B) * Tp <= Mp
+        Tm, Tp, Mp, r = self.zt_layout(b_first + B if b_total is None else b_total, T)
+        assert D3 == 3 * D and P == Mp + (256 if r else 0) and (b_first + B) * Tp <= Mp
         if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
             raise RuntimeError("hyena_ct: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
         for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b")):
@@ -451,8 +485,9 @@ class HipOps:
             y = torch.empty(B, T, D, dtype=torch.bfloat16, device=zt.device)
         with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
             _check(self.lib.evo_hyena_ct(zt.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(), _ptr(y),
-                                         _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, Mp, Tp, b_first * Tp,
-                                         1 if state_only else 0, yb_rows, y_row0, _stream()), "evo_hyena_ct")
+                                         _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, P, Tp, b_first * Tp,
+                                         Tm if r else 0, Mp + 8 * b_first, 1 if state_only else 0, yb_rows, y_row0, _stream()),
+                   "evo_hyena_ct")
         if state_only:
             return torch.view_as_complex(s_fin)
         self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}

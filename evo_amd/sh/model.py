@@ -379,13 +379,14 @@ class StripedHyena(nn.Module):
             # [16-channel group][x2 | x1 | v]: the projection GEMM writes that layout directly from a row-permuted copy of
             # its weight (built once per layer, with the layer's MFMA operand table).
             if self._hyena_ct_ok(x2d, blk, B, T):
-                # round 4, second form: z CHANNEL-MAJOR.  The pre-norm writes its rows with every batch row padded to a multiple of
-                # 8 positions, the projection's dense layer runs with swapped operands (result = z^T, the weight as it is -- no
+                # round 4, second form: z CHANNEL-MAJOR.  The pre-norm writes its rows in z^T's position order (HipOps.zt_layout: batch
+                # rows padded to a multiple of 64 positions, or -- T = 512 k + r, the bench shapes -- unpadded rows of 512 k positions with
+                # the last r tokens of every row in a tail block), the projection's dense layer runs with swapped operands (result = z^T, the weight as it is -- no
                 # regrouped copy) and the operator loads a lane's eight steps of a channel as 16 contiguous bytes straight into
                 # registers (csrc/hyena_ct.hip: no window in LDS); y BLOCKED as below.  Scoring and cached prefill alike.
                 table = self._mfma_table(blk)
                 xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
-                zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data)
+                zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data, B, T)
                 yb = ops.yblk_empty(B * T, D, zt.device)
                 if cache is None:
                     y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)

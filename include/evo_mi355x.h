@@ -161,11 +161,14 @@ int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias
  * zt_row0 + b * row_pitch + t.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into the registers
  * the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0 (16-byte loads),
  * zt_pitch % 256 == 0, zt_pitch * 3 D * 2 < 4 GiB, zt 16-byte aligned; positions between T and row_pitch may hold anything.
- * z_halo [B, 2, 3 D] bf16 in the REFERENCE's column order (rows = steps -2, -1) or NULL. */
+ * z_halo [B, 2, 3 D] bf16 in the REFERENCE's column order (rows = steps -2, -1) or NULL.
+ * tail_T != 0 (the "tail form", T = 512 k + r with r <= 8: tail_T = 512 k): tokens t >= tail_T of batch row b sit at position
+ * tail_pos0 + 8 b + (t - tail_T) instead (a tail block behind the main area, filled by the weight-streaming dense layer: rows of 512 k
+ * positions need no padding and the projection no extra round of tiles; evo_amd/ops.py zt_layout); row_pitch >= tail_T then. */
 int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                  const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                 int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t state_only, int64_t y_blocked_rows,
-                 int64_t y_row0, void* stream);
+                 int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t tail_T, int64_t tail_pos0, int64_t state_only,
+                 int64_t y_blocked_rows, int64_t y_row0, void* stream);
 
 /* The Hyena projection with a transposed result              [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections]:
  * zt [Mp / 256][N][256] bf16 = (x [Mp, K] . w [N, K]^T + bias [N])^T in blocks of 256 positions (an output tile of the kernel = one
@@ -174,10 +177,11 @@ int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const vo
  * layer's result, transposed.  Mp % 256 == 0 (the caller pads x: see evo_rmsnorm_rows_bf16), N % 256 == 0, K % 64 == 0, K >= 128. */
 int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N, int64_t K, void* stream);
 
-/* evo_rmsnorm_bf16 with the output rows of every batch row of T tokens at a pitch of Tp >= T rows: row b * T + t of x [M = B T, D]
- * -> row b * Tp + t of out [>= B Tp, D]; the pad rows are not written.  Same arithmetic, same bits per row. */
+/* evo_rmsnorm_bf16 with the output rows in the order of a channel-major z^T: token t < Tm of batch row b (row b * T + t of x [M = B T, D])
+ * -> row b * Tp + t of out (Tp >= Tm; the pad rows are not written), the last T - Tm tokens of a row -> the compact tail rows
+ * tail0 + b * (T - Tm) + (t - Tm).  Tm = T: no tail.  Same arithmetic, same bits per row. */
 int evo_rmsnorm_rows_bf16(void* x, const void* bias, const void* scale, void* out, int64_t M, int64_t D, float eps,
-                          int64_t T, int64_t Tp, void* stream);
+                          int64_t T, int64_t Tp, int64_t Tm, int64_t tail0, void* stream);
 
 /* ---- Hyena operator, recurrent (decode) form -----------------------------------------------------
  * replaces step_fir + step_iir                             [REF evo/generation.py:111-114,138-155]

@@ -60,15 +60,20 @@ def test_argument_validation_needs_no_gpu():
     assert lib.evo_linear_zg_mfma_bf16(None, None, None, None, 512, 256, 768, 128, None) == -1         # Mtot < M
     assert lib.evo_hyena_mfma_zg(None, None, None, None, None, None, None, None, None, None, 1, 16, 200, 2, None) == -1   # D != 128 H
     one = ctypes.c_void_p(16)                                                                       # (a non-null, 16-byte aligned pointer value: never dereferenced)
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 100, 0, 0, 0, 0, None) == -1   # row pitch % 8
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 200, 104, 0, 0, 0, 0, None) == -1   # z^T not whole 256-position blocks
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 3, 100, 256, 2, 256, 104, 0, 0, 0, 0, None) == -1   # rows beyond z^T
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 104, 4, 0, 0, 0, None) == -1   # first position % 8
-    assert lib.evo_hyena_ct(one, None, None, None, None, None, None, None, None, 2, 100, 256, 2, 256, 104, 0, 1, 0, 0, None) == -1  # state-only without s_out
+    # evo_hyena_ct(..., B, T, D, H, zt_pitch, row_pitch, zt_row0, tail_T, tail_pos0, state_only, y_blocked_rows, y_row0, stream)
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 100, 0, 0, 0, 0, 0, 0, None) == -1   # row pitch % 8
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 200, 104, 0, 0, 0, 0, 0, 0, None) == -1   # z^T not whole 256-position blocks
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 3, 100, 256, 2, 256, 104, 0, 0, 0, 0, 0, 0, None) == -1   # rows beyond z^T
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 104, 4, 0, 0, 0, 0, 0, None) == -1   # first position % 8
+    assert lib.evo_hyena_ct(one, None, None, None, None, None, None, None, None, 2, 100, 256, 2, 256, 104, 0, 0, 0, 1, 0, 0, None) == -1  # state-only without s_out
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 500, 1024, 0, 0, 0, None) == -1   # tail_T % 512
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 530, 256, 2, 1280, 512, 0, 512, 1024, 0, 0, 0, None) == -1   # more than 8 tail tokens
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 512, 1000, 0, 0, 0, None) == -1   # tail block inside the main area
     assert lib.evo_linear_t_mfma_bf16(None, None, None, None, 300, 768, 256, None) == -1              # Mp % 256
     assert lib.evo_linear_t_mfma_bf16(None, None, None, None, 512, 700, 256, None) == -1              # N % 256
-    assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 200, 64, 1e-6, 100, 96, None) == -1      # pitch < T
-    assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 250, 64, 1e-6, 100, 104, None) == -1     # M % T
+    assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 200, 64, 1e-6, 100, 96, 100, 0, None) == -1      # pitch < Tm
+    assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 250, 64, 1e-6, 100, 104, 100, 0, None) == -1     # M % T
+    assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 200, 64, 1e-6, 100, 96, 96, 100, None) == -1     # tail rows inside the main rows
     lib.evo_rope_append_decode_bf16.restype = ctypes.c_int
     assert lib.evo_rope_append_decode_bf16(None, None, None, None, ctypes.c_float(1.0), 1, 32, 128, 8, 8, 8, 8, None) == -1   # null tensors
     assert lib.evo_attn_fwd_causal_bf16(None, None, None, None, 1, 1, 4, 4, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, None) == -1

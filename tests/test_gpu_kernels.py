@@ -670,44 +670,53 @@ def test_hyena_ct_pad_positions_do_not_matter(ops):
         assert torch.equal(y, outs[0][0]) and torch.equal(torch.view_as_real(s), torch.view_as_real(outs[0][1]))
 
 
-def test_hyena_ct_row_subrange(ops):
+@pytest.mark.parametrize("T", [700, 1026])                   # (plain form | tail form with two tail tokens per row)
+def test_hyena_ct_row_subrange(ops, T):
     """`b_first`: the row groups of a sequence-parallel shard are launched on sub-ranges of the batch rows of ONE z^T tensor."""
     from evo_amd.hyena_tables import mfma_operand_table
-    B, T, D, H = 5, 700, 256, 2
+    B, D, H = 5, 256, 2
     prm = hyena_params(D, 110)
     fir_w, fir_b, poles, res, dskip = [t.to(DEV) for t in prm]
     z = bf(torch.randn(B, T, 3 * D, generator=gen(111))).to(DEV)
     tab = mfma_operand_table(poles, res, dskip)
     zt = _zt_of(ops, z, B, T)
     y_all = ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H)
-    assert torch.equal(ops.hyena_ct(zt, 2, T, fir_w, fir_b, tab, H, b_first=3), y_all[3:5])
+    assert torch.equal(ops.hyena_ct(zt, 2, T, fir_w, fir_b, tab, H, b_first=3, b_total=B), y_all[3:5])
     assert torch.equal(ops.hyena_ct(_zt_of(ops, z[1:4].contiguous(), 3, T), 3, T, fir_w, fir_b, tab, H), y_all[1:4])
     assert torch.equal(ops.zt_rows(zt, B, T, T - 2, 2), z[:, T - 2:])
 
 
-@pytest.mark.parametrize("B,T,D", [(3, 1003, 256), (1, 2500, 512), (8, 8193, 256), (2, 640, 4096)])
+@pytest.mark.parametrize("B,T,D", [(3, 1003, 256), (1, 2500, 512), (8, 8193, 256), (2, 640, 4096), (4, 1028, 256), (1, 16385, 512)])
 def test_rmsnorm_rows_and_transposed_projection_are_bitwise_the_plain_ones(ops, B, T, D):
-    """rmsnorm_rows + linear_t (the dense layer with swapped operands, bias along the rows) = rmsnorm + the plain hand-written dense
-    layer, transposed and with the batch rows at a pitch of Tp: bit for bit."""
+    """rmsnorm_rows + linear_t (the dense layer with swapped operands, bias along the rows; the tail tokens of the tail form through the
+    weight-streaming kernel) = rmsnorm + the plain hand-written dense layer, transposed and in z^T's position order: bit for bit."""
     x = bf(torch.randn(B * T, D, generator=gen(130))).to(DEV)
     scale = bf(1.0 + 0.1 * torch.randn(D, generator=gen(131))).to(DEV)
     w = bf(torch.randn(3 * D, D, generator=gen(132)) * D ** -0.5).to(DEV)
     b = bf(torch.randn(3 * D, generator=gen(133)) * 0.1).to(DEV)
-    Tp, Mp = ops.zt_geometry(B, T)
-    assert Tp % 8 == 0 and Tp >= T and Tp - T < ops.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp and ops.zt_shape_ok(B, T, 3 * D, D)
-    n_ref = ops.rmsnorm(x, None, scale, 1e-6)
+    Tm, Tp, Mp, r = ops.zt_layout(B, T)
+    assert Tp % 8 == 0 and Tp >= Tm and Tp - Tm < ops.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp and ops.zt_shape_ok(B, T, 3 * D, D)
+    assert (r == 0 and Tm == T) or (1 <= r <= 8 and Tm == T - r and Tm % 512 == 0 and Tp == Tm)
+    n_ref = ops.rmsnorm(x, None, scale, 1e-6).view(B, T, D)
     xp = ops.rmsnorm_rows(x, scale, 1e-6, B, T)
-    assert tuple(xp.shape) == (Mp, D)
-    assert torch.equal(xp[:B * Tp].view(B, Tp, D)[:, :T].reshape(B * T, D), n_ref)
-    assert bool((xp[:B * Tp].view(B, Tp, D)[:, T:] == 0).all()) and bool((xp[B * Tp:] == 0).all())
+    assert tuple(xp.shape) == (Mp + 16, D)
+    assert torch.equal(xp[:B * Tp].view(B, Tp, D)[:, :Tm], n_ref[:, :Tm])
+    assert bool((xp[:B * Tp].view(B, Tp, D)[:, Tm:] == 0).all()) and bool((xp[B * Tp:Mp] == 0).all())
+    if r:                                                                               # the tail tokens, compactly behind the main rows
+        assert torch.equal(xp[Mp:Mp + B * r].view(B, r, D), n_ref[:, Tm:]) and bool((xp[Mp + B * r:] == 0).all())
     for bias in (b, None):
-        zt = ops.linear_t(xp, w, bias)
-        assert tuple(zt.shape) == (Mp // 256, 3 * D, 256)
-        M256 = B * T // 256 * 256
-        z_ref = ops.linear_mfma(n_ref[:M256].contiguous(), w, bias)                     # [M256, 3 D] on the same kernel, plain orientation
-        got = ops.zt_rows(zt, B, T, 0, T).reshape(B * T, 3 * D)[:M256]
-        assert torch.equal(got, z_ref), int((got != z_ref).sum())
-        z_all = torch.nn.functional.linear(n_ref.float(), w.float(), None if bias is None else bias.float())
+        zt = ops.linear_t(xp, w, bias, B, T)
+        assert tuple(zt.shape) == (Mp // 256 + (1 if r else 0), 3 * D, 256)
+        # main area: the same kernel in the plain orientation on the same rows -- bit for bit on the whole 256-row tiles
+        z_main = ops.linear_mfma(xp[:Mp].contiguous(), w, bias)                           # [Mp, 3 D]
+        got_main = zt[:Mp // 256].permute(0, 2, 1).reshape(Mp, 3 * D)
+        assert torch.equal(got_main, z_main), int((got_main != z_main).sum())
+        if r:                                                                           # tail block: the weight-streaming kernel's rows
+            got_tail = ops.zt_rows(zt, B, T, Tm, r).reshape(B * r, 3 * D)
+            assert torch.equal(got_tail, ops._linear_small_m(xp[Mp:Mp + B * r], w, bias, None))
+            ref_tail = torch.nn.functional.linear(n_ref[:, Tm:].reshape(B * r, D).float(), w.float(), None if bias is None else bias.float())
+            assert (got_tail.float() - ref_tail).abs().max().item() <= 2.0 ** -7 * ref_tail.abs().max().item()
+        z_all = torch.nn.functional.linear(n_ref.reshape(B * T, D).float(), w.float(), None if bias is None else bias.float())
         err = (ops.zt_rows(zt, B, T, 0, T).reshape(B * T, 3 * D).float() - z_all).abs().max().item()
         assert err <= 2.0 ** -7 * z_all.abs().max().item(), err
 

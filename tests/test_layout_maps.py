@@ -186,21 +186,28 @@ def test_blocked_y_layout_and_the_dense_layers_gather():
     assert torch.equal(z2, zg)
 
 
-def test_ct_lane_positions_history_lanes_and_zt_geometry():
+def test_ct_lane_positions_history_lanes_and_zt_layout():
     """csrc/hyena_ct.hip: the index arithmetic of the channel-major form, replayed on the host.  Lane (la = lane & 15, lq = lane >> 4)
-    of a tile loads the eight positions row0 + b Tp + 512 tile + 32 la + 8 lq .. + 7 of a column of z^T (16 bytes); the two steps
-    before them are the last pair of lane `hist_src` (lane - 16, or lane + 47 for lq = 0), for lane 0 the last pair of lane 63 of
-    the previous tile, at the start of a row the halo / zeros.  Reassembling every channel's stream from these pieces must give
-    back the sequence, for ragged T, rows padded to Tp and several batch rows."""
+    of a tile loads eight consecutive positions of a column of z^T (16 bytes): in the main area position b Tp + 512 tile + 32 la + 8 lq,
+    in the tail form (T = 512 k + r, r <= 8: HipOps.zt_layout) the ragged last tile loads position tail0 + 8 b + 32 la + 8 lq; the two
+    steps before a lane's first are the last pair of lane `hist_src` (lane - 16, or lane + 47 for lq = 0), for lane 0 the last pair of
+    lane 63 of the previous tile, at the start of a row the halo / zeros.  Reassembling every channel's stream from these pieces must
+    give back the sequence -- ragged T, padded rows, several batch rows, both forms."""
     import torch
     from evo_amd.ops import HipOps
-    for (B, T) in ((3, 1100), (2, 513), (1, 37), (4, 1024)):
-        Tp, Mp = HipOps.zt_geometry(B, T)
-        assert Tp % 8 == 0 and 0 <= Tp - T < HipOps.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp
-        z = torch.arange(1, B * T + 1, dtype=torch.float32).view(B, T)            # one column: value = 1 + flat index (0 = "nothing")
-        col = torch.full((Mp,), -1.0)                                              # pad positions: a value that must never be used
-        col[:B * Tp].view(B, Tp)[:, :T] = z
-        pos_max = Mp - 8
+    forms = set()
+    for (B, T) in ((3, 1100), (2, 513), (1, 37), (4, 1024), (8, 1025), (2, 1032), (3, 520), (16, 513), (17, 513)):
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
+        forms.add(r > 0)
+        assert Tp % 8 == 0 and 0 <= Tp - Tm < HipOps.ZT_ALIGN and Mp % 256 == 0 and Mp >= B * Tp
+        assert (r == 0 and Tm == T) or (1 <= r <= 8 and Tm == T - r and Tm % 512 == 0 and B * r <= 16)
+        assert HipOps.zt_geometry(B, T) == (Tp, Mp)
+        P = Mp + (256 if r else 0)
+        z = torch.arange(1, B * T + 1, dtype=torch.float32).view(B, T, 1)          # one column: value = 1 + flat index (0 = "nothing")
+        col = HipOps.zt_from_rows(z, B, T, pad_value=-1.0).permute(1, 0, 2).reshape(P)   # pad positions: a value that must never be used
+        bb, tt = torch.meshgrid(torch.arange(B), torch.arange(T), indexing="ij")
+        assert torch.equal(col[HipOps.zt_positions(B, T, bb, tt)], z[..., 0])       # zt_positions is the layout zt_from_rows writes
+        pos_max = P - 8
         n_tiles = (T + 511) // 512
         for b in range(B):
             carry = None
@@ -208,7 +215,9 @@ def test_ct_lane_positions_history_lanes_and_zt_geometry():
                 rw = {}
                 for lane in range(64):
                     la, lq = lane & 15, lane >> 4
-                    p = min(b * Tp + tile * 512 + 32 * la + 8 * lq, pos_max)
+                    t0 = tile * 512
+                    base = Mp + 8 * b + (t0 - Tm) if (r and t0 >= Tm) else b * Tp + t0
+                    p = min(base + 32 * la + 8 * lq, pos_max)
                     rw[lane] = col[p:p + 8]
                 for lane in range(64):
                     la, lq = lane & 15, lane >> 4
@@ -223,22 +232,32 @@ def test_ct_lane_positions_history_lanes_and_zt_geometry():
                         if t >= T or t0 >= T:
                             continue                                               # masked steps (n_valid): whatever was loaded
                         got = (hist[i + 2] if i < 0 else rw[lane][i]).item()
-                        want = z[b, t].item() if t >= 0 else 0.0
+                        want = z[b, t, 0].item() if t >= 0 else 0.0
                         assert got == want, (B, T, b, tile, lane, i)
                 carry = rw[63][6:8]
-    # zt_rows: token-major rows out of z^T
-    B, T, C = 3, 13, 6
-    Tp, Mp = HipOps.zt_geometry(B, T)
-    zz = torch.randn(B, T, C)
-    zt = HipOps.zt_from_rows(zz, B, T)
-    assert tuple(zt.shape) == (Mp // 256, C, 256)
-    assert torch.equal(HipOps.zt_rows(zt, B, T, T - 2, 2), zz[:, T - 2:])
-    assert torch.equal(HipOps.zt_rows(zt, B, T, 0, T), zz)
-    # the kernel's byte offset of position p of column c: (p / 256) * C * 512 + (p % 256) * 2 behind the column base c * 512
-    flat = zt.reshape(-1)
-    for b in range(B):
-        for t in (0, 5, T - 1):
-            p = b * Tp + t
-            for c in (0, C - 1):
-                off = c * 512 + (p // 256) * C * 512 + (p % 256) * 2
-                assert flat[off // 2].item() == zz[b, t, c].item()
+    assert forms == {True, False}
+    # zt_rows: token-major rows out of z^T; the kernel's byte offset of position p of column c
+    for (B, T, C) in ((3, 13, 6), (2, 515, 4)):
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
+        zz = torch.randn(B, T, C)
+        zt = HipOps.zt_from_rows(zz, B, T)
+        assert tuple(zt.shape) == (Mp // 256 + (1 if r else 0), C, 256)
+        assert torch.equal(HipOps.zt_rows(zt, B, T, T - 2, 2), zz[:, T - 2:])
+        assert torch.equal(HipOps.zt_rows(zt, B, T, 0, T), zz)
+        flat = zt.reshape(-1)
+        for b in range(B):
+            for t in (0, 5, T - 4, T - 1):
+                p = int(HipOps.zt_positions(B, T, torch.tensor(b), torch.tensor(t)))
+                for c in (0, C - 1):
+                    off = c * 512 + (p // 256) * C * 512 + (p % 256) * 2
+                    assert flat[off // 2].item() == zz[b, t, c].item()
+    # the pre-norm's row map (csrc/elementwise.hip rms_out_row) = the positions of the main area + compact tail rows
+    for (B, T) in ((8, 1025), (3, 1100), (4, 1028)):
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
+        for row in range(B * T):
+            b, t = divmod(row, T)
+            out = b * Tp + t if t < Tm else Mp + b * (T - Tm) + (t - Tm)
+            if t < Tm:
+                assert out == int(HipOps.zt_positions(B, T, torch.tensor(b), torch.tensor(t)))
+            else:
+                assert Mp <= out < Mp + 16

@@ -38,7 +38,7 @@ for arg in sys.argv[1:]:
         fn.argtypes = [P] * 10 + [I] * 4 + [P]
     elif old == "ct":
         fn = lib.evo_hyena_ct
-        fn.argtypes = [P] * 9 + [I] * 10 + [P]
+        fn.argtypes = [P] * 9 + [I] * 12 + [P]
     else:
         fn = lib.evo_hyena_cs_zg
         fn.argtypes = [P] * 9 + [I] * 8 + [P]
@@ -51,7 +51,7 @@ for (B, T) in shapes:
     z = rn(B, T, 3 * D).bfloat16()
     ref, sref = ops.hyena_prefill(z, fir_w, fir_b, poles, res, dskip, H, want_state=True)
     zg = z[..., perm].view(B * T, D // 16, 48).transpose(0, 1).contiguous()          # [groups, B T, 48]
-    Tp, Mp = ops.zt_geometry(B, T)
+    Tm, Tp, Mp, r_tail = ops.zt_layout(B, T)
     zt = ops.zt_from_rows(z, B, T)                                                   # [Mp / 256, 3 D, 256]: batch rows at a pitch of Tp
     nbytes = B * T * D * 8
     y = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
@@ -65,7 +65,7 @@ for (B, T) in shapes:
                     poles.data_ptr(), B, T, D, H, st)
         elif old == "ct":
             rc = fn(zt.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), yb.data_ptr(), None, so, poles.data_ptr(),
-                    B, T, D, H, Mp, Tp, 0, 0, yb.shape[0] * 128, 0, st)
+                    B, T, D, H, zt.shape[0] * 256, Tp, 0, Tm if r_tail else 0, Mp, 0, yb.shape[0] * 128, 0, st)
         elif old == "rm":
             rc = fn(zg.data_ptr(), None, fir_w.data_ptr(), fir_b.data_ptr(), tab.data_ptr(), y.data_ptr(), None, so, poles.data_ptr(),
                     B, T, D, H, B * T, 0, 0, 0, st)
@@ -96,8 +96,8 @@ for (B, T) in shapes:
               f"bit-reproducible {same}", flush=True)
     xin = rn(B * T, D, std=1.0).bfloat16()
     wg = rn(3 * D, D, std=0.02).bfloat16()
-    xpad = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
-    xpad[:B * Tp].view(B, Tp, D)[:, :T] = xin.view(B, T, D)
+    xpad = torch.zeros(Mp + 16, D, dtype=torch.bfloat16, device=dev)
+    xpad[:B * Tp].view(B, Tp, D)[:, :Tm] = xin.view(B, T, D)[:, :Tm]
     for nm, call in (("group-major projection (mode 2)", lambda: ops.lib.evo_linear_zg_mfma_bf16(xin.data_ptr(), wg.data_ptr(), None, zg.data_ptr(), (B * T) // 256 * 256, B * T, 3 * D, D, st)),
                      ("transposed projection (swapped operands)", lambda: ops.lib.evo_linear_t_mfma_bf16(xpad.data_ptr(), wg.data_ptr(), None, zt.data_ptr(), Mp, 3 * D, D, st))):
         for _ in range(2):

@@ -23,8 +23,8 @@ names = ["wait loads", "barrier", "staged out + history", "FIR", "MFMA + scan + 
 cols = [0, 1, 8, 2, 3, 4]
 st = torch.cuda.current_stream().cuda_stream
 for (B, T) in ((8, 8193), (1, 131073)):
-    Tp, Mp = ops.zt_geometry(B, T)
-    zt = rn(Mp // 256, 3 * D, 256).bfloat16()
+    Tm, Tp, Mp, r_tail = ops.zt_layout(B, T)
+    zt = rn(Mp // 256 + (1 if r_tail else 0), 3 * D, 256).bfloat16()
     xp = rn(Mp, D).bfloat16(); wgt = rn(3 * D, D, std=0.02).bfloat16()
     for mode in ("after-GEMM x12", "back-to-back x12"):
         for _ in range(12):

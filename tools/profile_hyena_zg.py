@@ -16,8 +16,8 @@ poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().co
 res = (rn(D, 8, 2, std=0.25) * torch.sqrt(om).unsqueeze(-1) * 4).float().contiguous()
 dskip = rn(D, std=0.5).bfloat16(); tab = mfma_operand_table(poles, res, dskip)
 for (B, T) in ((8, 8193), (1, 131073)):
-    Tp, Mp = ops.zt_geometry(B, T)
-    zt = rn(Mp // 256, 3 * D, 256).bfloat16()
+    Tm, Tp, Mp, r_tail = ops.zt_layout(B, T)
+    zt = rn(Mp // 256 + (1 if r_tail else 0), 3 * D, 256).bfloat16()
     for _ in range(3):
         ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
     torch.cuda.synchronize()
