@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -186,7 +187,7 @@ class HipOps:
         # ... or on CHANNEL-MAJOR z^T (csrc/hyena_ct.hip: the projection launched with swapped operands, no input window in LDS);
         # False: group-major z and hyena_cs.hip
         self.hyena_ct_flag = True
-        self._xpad = {}                 # zero-initialised padded inputs of the swapped-operand projection, by (rows, D, device)
+        self._xpad = threading.local()  # per thread: the zero-initialised padded input of the swapped-operand projection (_xpad_buffer)
         self.last_hyena_io = {}
 
     def _t(self, name):
@@ -383,20 +384,28 @@ class HipOps:
         return (self.hyena_ct_flag and B * T >= 256 and N % 256 == 0 and N % 384 == 0 and K % 64 == 0 and K >= 128
                 and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and P * N * 2 < 0xfffffff0)
 
+    def _xpad_buffer(self, rows: int, D: int, device) -> torch.Tensor:
+        """The cached [rows, D] bf16 workspace of rmsnorm_rows: zero-initialised once, ONE shape at a time (a scoring run keeps its
+        shape; a new shape replaces the buffer) and one instance PER THREAD (callers that drive one HipOps from several threads --
+        the virtual ranks of the sequence-parallel tests, a server's worker threads -- must not share it: launches of different
+        threads are not ordered with each other)."""
+        key = (rows, D, str(device))
+        cur = getattr(self._xpad, "entry", None)
+        if cur is None or cur[0] != key:
+            cur = (key, torch.zeros(rows, D, dtype=torch.bfloat16, device=device))
+            self._xpad.entry = cur
+        return cur[1]
+
     def rmsnorm_rows(self, x: torch.Tensor, scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
         """RMSNorm of x [B T, D] written in the row order of zt_layout: -> [Mp + 16, D], row b T + t at its z^T position for t < Tm, the
-        B r tail tokens compactly at rows Mp + b r + (t - Tm) (the weight-streaming kernel's input).  The buffer is a cached workspace per
-        shape (the pad rows are zero and never written), valid until the next call with the same shape."""
+        B r tail tokens compactly at rows Mp + b r + (t - Tm) (the weight-streaming kernel's input).  The buffer is a cached workspace
+        (_xpad_buffer: the pad rows are zero and never written), valid until this thread's next call."""
         self._need(x, torch.bfloat16, "rmsnorm x")
         self._need(scale, torch.bfloat16, "rmsnorm scale")
         M, D = x.shape
         assert M == B * T
         Tm, Tp, Mp, r = self.zt_layout(B, T)
-        key = (Mp, D, x.device)
-        out = self._xpad.get(key)
-        if out is None:
-            self._xpad.clear()                               # (one shape at a time: a scoring run keeps its shape)
-            out = self._xpad[key] = torch.zeros(Mp + 16, D, dtype=torch.bfloat16, device=x.device)
+        out = self._xpad_buffer(Mp + 16, D, x.device)
         with self._t("rmsnorm"):
             _check(self.lib.evo_rmsnorm_rows_bf16(x.data_ptr(), None, scale.data_ptr(), out.data_ptr(), M, D, float(eps), T, Tp, Tm, Mp,
                                                   _stream()), "evo_rmsnorm_rows_bf16")

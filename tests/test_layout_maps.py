@@ -261,3 +261,25 @@ def test_ct_lane_positions_history_lanes_and_zt_layout():
                 assert out == int(HipOps.zt_positions(B, T, torch.tensor(b), torch.tensor(t)))
             else:
                 assert Mp <= out < Mp + 16
+
+
+def test_rmsnorm_rows_workspace_is_per_thread_and_per_shape():
+    """HipOps._xpad_buffer: the same tensor for the same shape on one thread, a fresh zeroed one for another shape, and never the
+    tensor another thread is using."""
+    import threading
+    import torch
+    from evo_amd.ops import HipOps
+    ops = HipOps.__new__(HipOps)                              # (no library needed for this helper)
+    ops._xpad = threading.local()
+    a = ops._xpad_buffer(8, 16, "cpu")
+    assert a.shape == (8, 16) and a.dtype == torch.bfloat16 and bool((a == 0).all())
+    a.fill_(1.0)
+    assert ops._xpad_buffer(8, 16, "cpu") is a                # cached
+    b = ops._xpad_buffer(12, 16, "cpu")
+    assert b is not a and bool((b == 0).all())                # another shape: a new zeroed buffer ...
+    c = ops._xpad_buffer(8, 16, "cpu")
+    assert c is not a and bool((c == 0).all())                # ... and one shape at a time
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(ops._xpad_buffer(8, 16, "cpu")))
+    t.start(); t.join()
+    assert seen[0] is not c and bool((seen[0] == 0).all())    # another thread: its own buffer
