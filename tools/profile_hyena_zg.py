@@ -15,7 +15,7 @@ mag = 1.0 - om; ang = (torch.rand(D, 8, generator=g, device=dev) * 2 - 1) * math
 poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous()
 res = (rn(D, 8, 2, std=0.25) * torch.sqrt(om).unsqueeze(-1) * 4).float().contiguous()
 dskip = rn(D, std=0.5).bfloat16(); tab = mfma_operand_table(poles, res, dskip)
-for (B, T) in ((8, 8193), (1, 131073)):
+for (B, T) in (((8, 8193), (1, 131073)) if os.environ.get("HC_SHAPES") is None else eval(os.environ["HC_SHAPES"])):
     Tm, Tp, Mp, r_tail = ops.zt_layout(B, T)
     zt = rn(Mp // 256 + (1 if r_tail else 0), 3 * D, 256).bfloat16()
     for _ in range(3):
