@@ -19,8 +19,10 @@
 //   places the wait at their first use, the top of the next iteration.
 //
 // Alignment: 16-byte loads need (position of step 0 of a batch row) % 8 == 0 -- the caller pads every batch row to a multiple of
-// 8 positions (HipOps.rmsnorm_rows writes the normalised rows at b * Tp + t; the pad positions hold finite garbage that is
-// masked exactly like the ragged end of the last tile).
+// 8 positions (HipOps.rmsnorm_rows writes the normalised rows at b * Tp + t; the pad positions hold anything: they are
+// masked exactly like the ragged end of the last tile).  Tail form (HtArgs.tail_T): for T = 512 k + r, r <= 8, the rows hold 512 k
+// positions (no padding) and the last r tokens of a row sit in a tail block behind the main area -- they are the whole ragged last
+// tile, which loads them from there (voff_of); the projection's dense layer then covers B * 512 k rows, a whole number of tiles.
 // Entry point and reference citation: include/evo_mi355x.h (evo_hyena_ct).
 #include "common.h"
 #include "../../include/evo_mi355x.h"
