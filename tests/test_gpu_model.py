@@ -104,6 +104,37 @@ def test_cached_decode_consistent_with_parallel_and_oracle():
     assert c["mha"].key_value_memory_dict[2].shape[2:] == (2, 2, 128)
 
 
+@pytest.mark.parametrize("P", [513, 1026, 600])             # prompt lengths: tail form of z^T with r = 1, r = 2; plain (padded) form
+def test_cached_prefill_through_both_forms_of_zt_then_decode(P):
+    """The cached prompt pass on the channel-major path (csrc/hyena_ct.hip): for P = 512 k + r the last r tokens of every row live in
+    the tail block of z^T, and the FIR state the cache keeps (the last two z rows) straddles the main area and the tail block.  The
+    decode steps that follow must continue the parallel forward of the whole sequence."""
+    from evo_amd.ops import HipOps
+    cfg, sd, m = build(SMALL)
+    B, n_new = 2, 6
+    ids = acgt(B, P - 1 + n_new)                              # BOS + P - 1 + n_new tokens
+    Tm, _, _, r = HipOps.zt_layout(B, P)
+    assert (r > 0) == (P % 512 in (1, 2)) and m._hyena_ct_ok(torch.empty(1, device=DEV), m.blocks[0], B, P)
+    full = m(ids.to(DEV))[0].float().cpu()
+    ref = R.RefStripedHyena(cfg, sd, "fp64")(ids)[0]
+    floor = rel_l2(R.RefStripedHyena(cfg, sd, "bf16")(ids)[0], ref)
+    tol = max(1.5 * floor, 4e-3)
+    c = m.initialize_inference_params()
+    c["mha"].max_batch_size = c["hyena"].max_batch_size = B
+    l0, c = m(ids[:, :P].to(DEV), c)
+    assert rel_l2(l0, ref[:, :P]) < tol and rel_l2(l0, full[:, :P]) < 2 * tol
+    steps = []
+    for t in range(P, P + n_new):
+        c["mha"].seqlen_offset = c["hyena"].seqlen_offset = t
+        lt, c = m(ids[:, t:t + 1].to(DEV), c)
+        steps.append(lt[:, 0].float().cpu())
+    steps = torch.stack(steps, 1)
+    print(f"[cached prefill P={P} (z^T tail tokens per row: {r})] prompt logits vs fp64 {rel_l2(l0, ref[:, :P]):.3e}, "
+          f"{n_new} decode steps vs fp64 {rel_l2(steps, ref[:, P:]):.3e} (tol {tol:.3e}), vs the parallel forward {rel_l2(steps, full[:, P:]):.3e}")
+    assert rel_l2(steps, ref[:, P:]) < tol
+    assert rel_l2(steps, full[:, P:]) < 2 * tol
+
+
 def test_evo_api_scores_vs_oracle():
     import evo_amd
     from evo_amd.tokenizer import CharLevelTokenizer
