@@ -50,22 +50,46 @@ def is_stale() -> bool:
     return newest > out.stat().st_mtime
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source into one shared library.  Returns the library path."""
-    out = lib_path()
-    if not force and not is_stale():
-        return out
-    LIBDIR.mkdir(exist_ok=True)
-    tmp = out.with_suffix(".so.tmp%d" % os.getpid())
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wno-inline-asm", "-o", str(tmp)] + os.environ.get("EVO_AMD_HIPCC_FLAGS", "").split() \
-        + [str(s) for s in sources()]
+# per-file compiler flags.  attn_w64.hip: its softmax streams are scalar fp32 on purpose (beside MFMAs a packed v_pk_* instruction costs
+# more than the two it replaces), so the SLP vectoriser stays off for that file
+FILE_FLAGS = {"attn_w64.hip": ["-fno-slp-vectorize", "-Wno-unused-value"]}
+
+
+def _compile_one(args):
+    src, obj, verbose = args
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-inline-asm"] \
+        + os.environ.get("EVO_AMD_HIPCC_FLAGS", "").split() + FILE_FLAGS.get(src.name, []) + ["-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
-    os.replace(tmp, out)
+        raise RuntimeError(f"hipcc failed on {src.name}:\n" + proc.stdout + proc.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source (one object per file, in parallel) and link them into one shared library.  Returns the library path."""
+    out = lib_path()
+    if not force and not is_stale():
+        return out
+    LIBDIR.mkdir(exist_ok=True)
+    objdir = LIBDIR / ("obj%d" % os.getpid())
+    objdir.mkdir(exist_ok=True)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = [(s, objdir / (s.stem + ".o"), verbose) for s in sources()]
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            objs = list(ex.map(_compile_one, jobs))
+        tmp = out.with_suffix(".so.tmp%d" % os.getpid())
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", str(tmp)] + [str(o) for o in objs]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc (link) failed:\n" + proc.stdout + proc.stderr)
+        os.replace(tmp, out)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return out
 
 

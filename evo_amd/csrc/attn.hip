@@ -21,50 +21,7 @@
 #include "common.h"
 #include "../../include/evo_mi355x.h"
 
-#define QB 128
-#define KB 64
-#define DH 128
-
-typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ mfma_bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(mfma_bf16x8, v); }
-
-struct AttnArgs {
-    const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o;
-    int64_t Tq, Tk, q_pos0;
-    int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh;
-    int H;
-    float scale_log2;      // softmax_scale * log2(e)
-    int n_qblocks;
-    // decode (split-K) mode only
-    const int64_t* dyn_pos;   // device int64 [B]: position of each row's (single) query; overrides Tk / q_pos0 when non-null
-    float* part_o;            // [B, H, n_splits, 128] unnormalised partial outputs
-    float* part_ml;           // [B, H, n_splits, 2]   running max (log2 domain) and denominator
-    int n_splits;
-    int nbh;                  // B * H (prefill: 1-D grid of n_qblocks * nbh workgroups)
-};
-
-// Workgroup -> (query block, head, batch) for the prefill kernel, 1-D grid.  Blocks are dispatched round-robin
-// over the 8 XCDs (block b -> XCD b % 8), each with a private L2.  All query blocks of one (batch, head) re-stream
-// the same K/V, so they are pinned to ONE XCD -- (batch, head) pair number p lives on XCD p % 8 -- and issued
-// longest-first within it, which keeps the co-resident workgroups walking the same key tiles at the same time.
-// (With the plain (qblock, head, batch) grid every XCD fetched every head: L2 hit rate ~40 %, 5.2 GB fetched for
-// 268 MB of K/V at T = 16,385; pinned: 89-92 % and 1.9 GB, +5...9 % throughput.)  Placement only affects speed.
-__device__ __forceinline__ void attn_block_map(const AttnArgs& a, int& qb, int& head, int& bat) {
-    const int bid = blockIdx.x;
-    int pair, qi;
-    if (a.nbh % 8 == 0) {
-        const int xcd = bid & 7, slot = bid >> 3;          // slot-th block of this XCD
-        qi = slot % a.n_qblocks;
-        pair = (slot / a.n_qblocks) * 8 + xcd;
-    } else {
-        qi = bid % a.n_qblocks;
-        pair = bid / a.n_qblocks;
-    }
-    qb = a.n_qblocks - 1 - qi;                              // longest (latest) query blocks first
-    head = pair % a.H;
-    bat = pair / a.H;
-}
+#include "attn_common.h"
 
 // DECODE = true: one query row per (batch, head); blockIdx.x is a SPLIT of the key range ("flash-decoding"):
 // every split streams its share of the KV cache and leaves an unnormalised partial (O, m, l) that
@@ -838,10 +795,13 @@ extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void
     a.H = (int)H;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
     a.dyn_pos = nullptr; a.part_o = nullptr; a.part_ml = nullptr; a.n_splits = 1;
-    // long query ranges take the pipelined 256-row kernel (EVO_AMD_ATTN_PIPE=0 keeps everything on the 128-row one)
-    static const int pipe_on = [] { const char* e = getenv("EVO_AMD_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-    const int use_pipe = pipe_on && Tq > QB;
+    // query ranges longer than one 128-row block take the 64-rows-per-wave kernel of csrc/attn_w64.hip; EVO_AMD_ATTN_FORM = 1 keeps
+    // them on the 8-wave pipelined kernel of rounds 2-4 (A/B measurements), 0 on the 128-row kernel
+    static const int form = [] { const char* e = getenv("EVO_AMD_ATTN_FORM"); return e ? atoi(e) : 2; }();
     a.nbh = (int)(B * H);
+    a.q_pad = 0;
+    if (form >= 2 && Tq > QB) return evo_attn_w64_launch(a, B, stream);
+    const int use_pipe = form >= 1 && Tq > QB;
     const int qblock = use_pipe ? PQB : QB;
     a.n_qblocks = (int)((Tq + qblock - 1) / qblock);
     const int64_t n_wg = (int64_t)a.n_qblocks * a.nbh;
@@ -868,7 +828,7 @@ extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v,
     a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
     a.H = (int)H;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    a.n_qblocks = 1;
+    a.n_qblocks = 1; a.q_pad = 0;
     a.dyn_pos = dyn_pos; a.part_o = part_o; a.part_ml = part_ml; a.n_splits = (int)n_splits; a.nbh = (int)(B * H);
     hipStream_t s = (hipStream_t)stream;
     // EVO_ATTN_DECODE_FORM=0 keeps the MFMA split kernel (measurement builds); default: the streaming kernel, one split per wave

@@ -1,0 +1,549 @@
+// Causal attention forward for gfx950, head dim 128 -- the prefill kernel of round 5 (query ranges longer than one 128-row block).
+// Same arithmetic contract as csrc/attn.hip (bf16 in, fp32 scores / softmax / accumulate, P rounded to bf16 for P.V, bf16 out:
+// FlashAttention-2's numerics, which is what the reference runs [REF README.md:47-50; evo-1-131k-base_inference.yml:30]) and the
+// same "swapped" MFMA forms (S^T = K Q^T, O^T = V^T P^T on v_mfma_f32_32x32x16_bf16: a lane owns one query column, so the softmax
+// statistics are lane-local).  What changes is the shape of the work a wave does:
+//
+//   * a workgroup is 4 waves = ONE wave per SIMD, each with the whole 512-register file, and a wave owns 64 query rows (two 32-row
+//     MFMA column blocks).  Every K fragment (ds_read_b128) and every V^T fragment pair (ds_read_b64_tr_b16) read from LDS feeds
+//     TWO MFMAs -- half the LDS fragment traffic per flop of the 8 x 32-row kernel (profiles/r03_attn_notes.txt: 290 KB per 64-key
+//     tile and CU there), and no second wave competing for the SIMD's matrix pipe and VALU issue slots;
+//   * a 64-key tile costs a wave 64 MFMAs (2 x 32) and ~350 other instructions (64 scores per lane: scale / subtract, exp2, row sum,
+//     bf16 pack, row max; 48 LDS fragment reads; 8-9 LDS-DMA pieces).  A 32x32x16 MFMA occupies the pipe for 32 cycles, which hides
+//     ~5 single-issue instructions, so the softmax is cut into two streams that ride under BOTH MFMA phases of a trip:
+//        phase 1:  QK^T(t+1)  ||  exp / sum / pack of the last 3/4 of tile t's scores, K fragment reads (second half of K(t+1))
+//        phase 2:  P.V(t)     ||  row max of S(t+1), the running-max bookkeeping, exp / sum / pack of the FIRST quarter of S(t+1),
+//                                 V^T fragment reads, the first-half K fragments of tile t+2, the DMA pieces of K(t+4) / V(t+2)
+//     Program order IS the schedule (sched_barrier after every MFMA's chunk).  Nothing sits between the phases except the (rare)
+//     masking of a diagonal / ragged tile and the (rare) rescale of O;
+//   * K tiles live in a 4-deep LDS ring, V tiles in a 3-deep one, both filled by LDS-DMA (buffer_load ... lds, 1 KiB per
+//     wave-instruction).  K runs one tile further ahead than the 8-wave kernel's so that the K fragments a trip starts with are read
+//     BEFORE the trip's barrier, under the previous trip's P.V MFMAs: with one wave per SIMD nobody else covers an LDS round trip
+//     at the head of a trip.  ONE barrier per tile;
+//   * the running max is DEFERRED per row: a row's reference point m only moves when the tile's scaled maximum exceeds it by more
+//     than W_THR (log2 units), otherwise P = 2^(s c - m) <= 2^W_THR is used as it is -- P, l and O are floating point with fp32 /
+//     bf16 exponent range, so a common factor of up to 2^W_THR costs no precision, and the O rescale (128 accumulator registers per
+//     lane) almost never runs after a row's first tiles instead of on most tiles of an 8k row.  The decision is PER ROW (rows that
+//     do not move get alpha = 1 exactly), so a row's arithmetic never depends on which other rows share its wave: outputs stay
+//     bit-identical across query offsets / launch geometries (tests/test_gpu_fullsize.py).  W_THR = 0 is the textbook update;
+//   * query blocks are aligned to the END of the query range (block 0 is the short one).  T = 2^k + 1 (a BOS token in front of 2^k
+//     nucleotides) then costs one extra 1-tile block instead of a whole 256-row block walking all 2^k / 64 + 1 tiles for ONE row
+//     (+6 % tiles at 8 x 8,193);
+//   * O^T leaves through v_permlane32_swap pairs as 16-byte stores (8 per 32-row block and lane instead of 16 x 8 bytes).
+//
+// LDS images: K [64 keys][272 B] (padded rows: b128 fragment reads conflict-free, per-lane base + immediates), V [64 keys][256 B]
+// with the 64-byte blocks of a row XOR-swizzled by (key & 3) on the DMA's source side (ds_read_b64_tr_b16 conflict-free) -- as in
+// attn_fwd_pipe_kernel, whose fragment address maps are reused unchanged.
+#include <stdlib.h>
+#include <utility>
+#include "attn_common.h"
+#include "../../include/evo_mi355x.h"
+
+#define W_QB 256
+#define W_KROW 272
+#define W_KSTAGE (KB * W_KROW)              // 17,408 B = 17 DMA pieces
+#define W_VSTAGE (KB * 256)                 // 16,384 B = 16 DMA pieces
+#define W_NK 4
+#define W_NV 3
+#define W_VBASE (W_NK * W_KSTAGE)           // 69,632
+#define W_LDS (W_VBASE + W_NV * W_VSTAGE)   // 118,784 B
+#ifndef W_THR
+#define W_THR 8.0f                          // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
+#endif
+#ifndef W_VD
+#define W_VD 4                              // V^T fragment pairs read ahead of their MFMAs
+#endif
+#define W_NG_EARLY 4                        // exp groups (2 x 2 scores x ... = 14 instructions each) done under the previous trip's P.V
+
+typedef int w_srd_t __attribute__((ext_vector_type(4)));
+typedef unsigned int w_u32x4 __attribute__((ext_vector_type(4)));     // asm operands must be native vectors (a HIP uint4 is a struct)
+typedef unsigned int w_u32x2 __attribute__((ext_vector_type(2)));
+
+// value of lane ^ 32, combined with max / add (v_permlane32_swap: one VALU instruction, no LDS round trip)
+__device__ __forceinline__ float w_xor32_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float w_xor32_add(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+#define W_WAIT(K)                                                                                    \
+    do {                                                                                             \
+        if (np == 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 * (K)) : "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (K)) : "memory");                          \
+    } while (0)
+#define W_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// MFMAs and LDS fragment reads are inline asm with the register FILE of every operand spelled out: O^T accumulators (128), Q fragments
+// (64) and K fragments (32) live in the AGPR half of the wave's 512 registers, scores / P / V^T fragments and the softmax arithmetic
+// in the VGPR half (left to itself hipcc splits the accumulators between the files and moves ~1,200 v_accvgpr_read / write per trip,
+// spilling 83 registers to scratch).  The compiler neither inserts waits for asm LDS reads nor hazard padding behind asm MFMAs:
+//   * LDS reads return in order; every consumer MFMA is preceded by a COUNTED s_waitcnt lgkmcnt(N), N = the LDS instructions issued
+//     after its fragment's read (w_wait_* below replay the program order of a trip); a trip ends with lgkmcnt(0), 9 MFMAs behind its
+//     last read;
+//   * an accumulator is read by other instructions only >= 4 MFMAs (128 cycles) after the last MFMA that wrote it, or behind 24
+//     explicit wait states (masking / rescale / epilogue paths).
+#define W_MFMA_S0(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(S) : "a"(KF), "a"(QF))
+#define W_MFMA_S(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S) : "a"(KF), "a"(QF))
+#define W_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(O) : "v"(VF), "v"(PF))
+#define W_DSR_K(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
+#define W_DSR_TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+// (hipcc does not capture a local that a generic lambda names ONLY in asm operands: name it once outside of them)
+#define W_USE2(A, B) (void)(A), (void)(B)
+#define W_USE3(A, B, C) (void)(A), (void)(B), (void)(C)
+// An instruction the compiler emits for the softmax streams has no tie to the volatile asm sequence: instruction selection would sink
+// it to its first real use (all 64 exp2 behind the last QK^T MFMA).  W_PIN names its result as an INPUT of an empty volatile asm right
+// behind it, which puts it in its gap (an input does not make the recognizer pad anything; an asm OUTPUT read by the next instruction does).
+#define W_PIN(X) asm volatile("" ::"v"(X))
+#define W_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#define W_NOP24()                                                        \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+
+// LDS instructions of a trip in program order (inside a gap: [wait] MFMA, V^T pair reads, K read):
+//   phase 1, gap i:  odd i < 16: the second-half K fragment of k-step i / 2;   even i >= 32 - 2 W_VD: V^T pair (i - (32 - 2 W_VD)) / 2
+//   phase 2, gap j:  even j: V^T pair j / 2 + W_VD (while < 16);   even 8 <= j <= 22: the first-half K fragment (j - 8) / 2 of the next tile
+constexpr int w_p1_ops(int i) { return (((i & 1) && i < 16) ? 1 : 0) + ((i >= 32 - 2 * W_VD && !(i & 1)) ? 2 : 0); }
+constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 2 : 0) + ((!(j & 1) && j >= 8 && j <= 22) ? 1 : 0); }
+constexpr int w_wait_k1(int ks) {           // before the MFMA of phase-1 gap 16 + 2 ks: LDS instructions behind the refill of gap 2 ks + 1
+    int n = 0;
+    for (int i = 2 * ks + 2; i < 16 + 2 * ks; ++i) n += w_p1_ops(i);
+    return n;
+}
+constexpr int w_wait_v(int p) {             // before the MFMA of phase-2 gap 2 p: LDS instructions behind the read of V^T pair p
+    int n = 0;
+    if (p < W_VD) {
+        for (int i = 32 - 2 * W_VD + 2 * p + 1; i < 32; ++i) n += w_p1_ops(i);
+        for (int j = 0; j < 2 * p; ++j) n += w_p2_ops(j);
+    } else {
+        const int j0 = 2 * (p - W_VD);
+        n += (j0 >= 8 && j0 <= 22) ? 1 : 0;
+        for (int j = j0 + 1; j < 2 * p; ++j) n += w_p2_ops(j);
+    }
+    return n;
+}
+static_assert(W_VD >= 1 && W_VD <= 8, "V^T read-ahead distance");
+
+// compile-time loops: the asm operands that are immediates (LDS offsets, lgkmcnt counts) need integer constant expressions
+template <int I> struct w_ic { static constexpr int v = I; };
+template <class F, int... Is>
+__device__ __forceinline__ void w_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(w_ic<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void w_static_for(F&& f) { w_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..3
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int np = wave == 0 ? 9 : 8;                                   // DMA pieces of this wave per trip (17 K + 16 V over 4 waves)
+
+    const int64_t Tk_ = a.Tk, q_pos0_ = a.q_pos0;
+    int qblk, head, bat;
+    attn_block_map(a, qblk, head, bat);
+    const int64_t q0 = (int64_t)qblk * W_QB - a.q_pad;                  // block 0 starts q_pad rows before the range (those rows: clamped, not stored)
+    const uint16_t* qp = a.q + bat * a.q_sb + head * a.q_sh;
+    const unsigned char* kp = (const unsigned char*)(a.k + bat * a.k_sb + head * a.k_sh);
+    const unsigned char* vp = (const unsigned char*)(a.v + bat * a.v_sb + head * a.v_sh);
+    const int64_t kst_b = a.k_st * 2, vst_b = a.v_st * 2;
+
+    // ---- this lane's two query rows (column l31 of the wave's two 32-row blocks) ---------------------------------------------------
+    const int64_t wrow0 = q0 + wave * 64;                               // wave-uniform
+    int64_t qrow[2];
+    w_u32x4 qf[2][8];                                                   // Q fragments: AGPRs from here on (only ever "a" operands)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        qrow[x] = wrow0 + 32 * x + l31;
+        const int64_t qc = qrow[x] < 0 ? 0 : qrow[x];                   // (rows past the end cannot occur: blocks end at Tq)
+        const w_u32x4* qr = (const w_u32x4*)(qp + qc * a.q_st);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[x][ks] = qr[2 * ks + half];
+    }
+    // key limit of a lane's row relative to the wave's first (clamped) row position; the mask path adds the wave-uniform part
+    const int64_t wpos0 = (wrow0 < 0 ? 0 : wrow0) + q_pos0_;           // position of the wave's first valid row: min over the wave
+    int lim_rel[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) lim_rel[x] = (int)((qrow[x] < 0 ? 0 : qrow[x]) + q_pos0_ - wpos0);      // 0..63
+    const bool row_ok0 = qrow[0] >= 0, row_ok1 = qrow[1] >= 0;
+    const int64_t orow_first = (qrow[0] < 0 ? 0 : qrow[0]);            // (epilogue: output rows of the lane)
+    const int64_t orow_second = (qrow[1] < 0 ? 0 : qrow[1]);
+
+    int64_t max_key = q0 + W_QB - 1 + q_pos0_;                          // (q0 + 255 <= Tq - 1 by construction)
+    if (max_key > Tk_ - 1) max_key = Tk_ - 1;
+    const int n_tiles = (int)(max_key / KB) + 1;
+
+    // ---- DMA plan ---------------------------------------------------------------------------------------------------------------
+    // K piece j (17 of 1 KiB: padded rows) -> waves j % 4, five per-lane offsets; V piece j (16: 4 rows each) -> one per-lane offset
+    // (row (lane >> 4) of the piece, 64-byte block XOR (row & 3)) + a wave-uniform row offset in the instruction's SGPR offset.
+    uint32_t dk_off[5];
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+        const int j = wave + 4 * jj;
+        const int pos = j * 1024 + 16 * lane;
+        const int r = pos / W_KROW;
+        int c = pos - r * W_KROW;
+        c = c < 256 ? c : 0;                                            // pad lanes re-fetch the row's first granule (never read back)
+        dk_off[jj] = (uint32_t)r * (uint32_t)kst_b + (uint32_t)c;
+    }
+    uint32_t dv_off;
+    {
+        const int r = lane >> 4;
+        int c = (lane & 15) * 16;
+        c = ((((c >> 6) ^ r) & 3) << 6) | (c & 63);
+        dv_off = (uint32_t)r * (uint32_t)vst_b + (uint32_t)c;
+    }
+    const uint32_t dv_soff = (uint32_t)(4 * vst_b);                    // per V piece: 4 rows
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // Buffer descriptors of one tile: base = its first row, num_records = bytes up to the end of the last VALID key (0 past the end):
+    // the hardware bounds check returns zeros beyond -- no clamping, every trip issues the same instructions.  Branch-free scalar code:
+    // tiles below n_full are whole, tile n_full holds the Tk % 64 last keys, later ones nothing.
+    const int n_full = (int)(Tk_ / KB), k_rem = (int)(Tk_ % KB);
+    auto tile_srd = [&](const unsigned char* base, int64_t st_b, int tile) __attribute__((always_inline)) {
+        const uint32_t rec_full = (uint32_t)((KB - 1) * st_b + 256);
+        const uint32_t rec_rem = k_rem ? (uint32_t)((k_rem - 1) * st_b + 256) : 0u;
+        const uint64_t a64 = (uint64_t)base + (uint64_t)(uint32_t)tile * (uint64_t)(KB * st_b);
+        w_srd_t d;
+        d[0] = (int)(uint32_t)a64;
+        d[1] = (int)(uint32_t)(a64 >> 32);
+        d[2] = (int)(tile < n_full ? rec_full : (tile == n_full ? rec_rem : 0u));
+        d[3] = 0x00020000;
+        return d;
+    };
+// One DMA piece = "m0 <- LDS address" + the load.  In the prologue both in one asm; inside a trip the m0 write heads the gap and the load
+// ends it (W_M0_* / W_LD_*): the MFMA between them is the wait state the pair needs, and the piece costs two issue slots instead of four.
+#define W_DMA_K(SRD, SLOT_LDS, JJ)                                                                              \
+    {                                                                                                           \
+        const int j_ = wave + 4 * (JJ);                                                                         \
+        if ((JJ) < 4 || j_ < 17)                                                                                \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"               \
+                         ::"s"((SLOT_LDS) + j_ * 1024), "v"(dk_off[JJ]), "s"(SRD) : "memory", "m0");            \
+    }
+#define W_DMA_V(SRD, SLOT_LDS, JJ)                                                                              \
+    {                                                                                                           \
+        const int j_ = wave + 4 * (JJ);                                                                         \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"                  \
+                     ::"s"((SLOT_LDS) + j_ * 1024), "v"(dv_off), "s"(SRD), "s"(j_ * dv_soff) : "memory", "m0"); \
+    }
+#define W_M0(SLOT_LDS, PIECE) asm volatile("s_add_u32 m0, %0, %1" ::"s"(SLOT_LDS), "s"((wave + 4 * (PIECE)) * 1024) : "memory", "m0", "scc")
+#define W_LD_K(SRD, JJ) asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(dk_off[JJ]), "s"(SRD) : "memory")
+#define W_LD_V(SRD, JJ) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dv_off), "s"(SRD), "s"((wave + 4 * (JJ)) * dv_soff) : "memory")
+#define W_KSLOT(T) (lds0 + (uint32_t)((T) & (W_NK - 1)) * W_KSTAGE)
+#define W_VSLOT(T) (lds0 + W_VBASE + (uint32_t)((T) % W_NV) * W_VSTAGE)
+    auto dma_k = [&](int tile) __attribute__((always_inline)) {
+        const w_srd_t s_ = tile_srd(kp, kst_b, tile);
+        const uint32_t st_ = W_KSLOT(tile);
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) W_DMA_K(s_, st_, jj);
+    };
+    auto dma_v = [&](int tile) __attribute__((always_inline)) {
+        const w_srd_t s_ = tile_srd(vp, vst_b, tile);
+        const uint32_t st_ = W_VSLOT(tile);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) W_DMA_V(s_, st_, jj);
+    };
+
+    // per-lane fragment addresses inside a stage (everything else is an immediate): the maps of attn_fwd_pipe_kernel
+    const uint32_t k_rd = lds0 + (uint32_t)(l31 * W_KROW + half * 16);
+    uint32_t v_rd[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int r0 = ((lane & 15) >> 2) + 4 * half;
+        v_rd[dt] = lds0 + (uint32_t)(W_VBASE + r0 * 256 + ((dt ^ (r0 & 3)) << 6) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    }
+
+    f32x16_t oacc[2][4];                          // O^T accumulators: AGPRs
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[x][dt][r] = 0.f;
+            asm volatile("" : "+a"(oacc[x][dt]));
+        }
+    // Online softmax state of the lane's two rows.  A row's exponentials are taken relative to a reference point -nm (scaled, log2
+    // domain) that moves only when a tile's largest exponent exceeds W_THR (or at the row's first visible key); `seen` = it has one.
+    float nm[2] = {0.f, 0.f};                     // -(reference point); 0 until the row has seen a key
+    bool seen[2] = {false, false};
+    float l_run[2] = {0.f, 0.f};                  // this lane's share of the row's denominator
+    float alpha[2] = {1.f, 1.f};                  // factor the pending tile applies to l (and to O when `resc`)
+    float psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
+    bool resc = false;                            // wave-uniform: some row of the wave moved its reference point for the pending tile
+    const float c_sc = a.scale_log2;
+
+    f32x16_t S[2][2];                             // score tile of the NEXT tile [query block][32-key half]: VGPRs, MFMA outputs only
+    float ev[2][32];                              // its exponents s c - reference, then (next trip) the current tile's: [x][16 kt + r]
+    uint32_t pk[2][16];                           // bf16-packed P^T of the current tile [query block][4 * (16-key group) + word]
+    w_u32x4 kf[8];                                // K fragments (one 32-key half, 8 k-steps): AGPRs
+
+    // ---- phase-1 stream: P = 2^e, row sums, bf16 pack -- 160 instructions, in the order P.V consumes the words ------------------------
+    // unit u: 16-key group g = u >> 3, query block x = (u >> 2) & 1, word w = u & 3 (two scores);  group G = units 2G, 2G+1:
+    // 10 instructions: 4 x exp2, 4 x add, 2 x pack
+    float tp[4];
+    auto exp_op = [&](const int G, const int o) __attribute__((always_inline)) {
+        const int which = o < 8 ? ((o & 3) >> 1) : (o - 8);
+        const int u = 2 * G + which;
+        const int g = u >> 3, x = (u >> 2) & 1, w = u & 3;
+        const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;                     // index into ev[x]: 16 kt + register of the MFMA tile
+        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(ev[x][r + (o & 1)]); W_PIN(tp[o]); }
+        else if (o < 8) {
+            const bool first_of_row = (u & 3) == 0 && g == 0 && which == 0;          // the tile's first unit of this query block
+            if ((o & 1) == 0) { psa[x] = first_of_row ? tp[o - 4] : psa[x] + tp[o - 4]; W_PIN(psa[x]); }
+            else { psb[x] = first_of_row ? tp[o - 4] : psb[x] + tp[o - 4]; W_PIN(psb[x]); }
+        } else { pk[x][4 * g + w] = pack_bf2(tp[2 * which], tp[2 * which + 1]); W_PIN(pk[x][4 * g + w]); }
+    };
+
+    // ---- phase-2 side stream on the NEXT tile's scores: exponents, row max, the reference-point bookkeeping --------------------------
+    // every instruction is the compiler's own (it pads its hazards; fmaxf of FMA results needs no canonicalising v_max; the file is
+    // built with -fno-slp-vectorize: beside MFMAs a packed fp32 instruction costs more than the two it replaces)
+    float tmx[2], dl[2] = {0.f, 0.f};
+    bool upd_any = false;
+    auto fma_op = [&](const int kt, const int k) __attribute__((always_inline)) {                               // k = 0..31: x = k >> 4, r = k & 15
+        const int x = k >> 4, r = k & 15;
+        ev[x][16 * kt + r] = __builtin_fmaf(S[x][kt][r], c_sc, nm[x]);
+        W_PIN(ev[x][16 * kt + r]);
+    };
+    auto max_op = [&](const int k) __attribute__((always_inline)) {              // k = 0..31: x = k & 1 (the two chains alternate), step k >> 1
+        const int x = k & 1, st = k >> 1;
+        const float* e = ev[x];
+        if (st == 0) tmx[x] = fmaxf(fmaxf(e[0], e[1]), e[2]);
+        else if (st < 15) tmx[x] = fmaxf(fmaxf(tmx[x], e[2 * st + 1]), e[2 * st + 2]);
+        else tmx[x] = fmaxf(tmx[x], e[31]);
+        W_PIN(tmx[x]);
+    };
+    auto book = [&](const int x) __attribute__((always_inline)) {
+        const float emax = w_xor32_max(tmx[x]);            // the row's largest exponent in this tile (-inf: all masked)
+        const bool first = !seen[x];
+        const bool upd = first ? (emax > -INFINITY) : (emax > W_THR);
+        dl[x] = upd ? emax : 0.f;
+        alpha[x] = first ? 0.f : __builtin_amdgcn_exp2f(-dl[x]);                // (l and O are still 0 for a row without a key); 1 exactly when it stays
+        nm[x] -= dl[x];
+        seen[x] = seen[x] || upd;
+        upd_any = upd_any || __any(upd);
+        W_PIN(alpha[x]); W_PIN(nm[x]); W_PIN(dl[x]);
+    };
+    // side work of P.V gap j: 120 instructions spread at <= 4 per gap; the second-half score tuples (last written by the MFMAs of
+    // phase-1 gaps 30 / 31) are first read in gap 8
+    auto side = [&](const int j) __attribute__((always_inline)) {
+        // (no loops here: a loop that contains a pin is unrolled too late for the register promotion of S / ev)
+        if (j < 8) {                                // exponents of the first-half tuples (written >= 16 MFMAs ago)
+            fma_op(0, 4 * j); fma_op(0, 4 * j + 1); fma_op(0, 4 * j + 2); fma_op(0, 4 * j + 3);
+        } else if (j < 16) {                        // ... of the second-half tuples
+            fma_op(1, 4 * (j - 8)); fma_op(1, 4 * (j - 8) + 1); fma_op(1, 4 * (j - 8) + 2); fma_op(1, 4 * (j - 8) + 3);
+        } else if (j < 24) {                        // row max: 16 steps per query block
+            max_op(4 * (j - 16)); max_op(4 * (j - 16) + 1); max_op(4 * (j - 16) + 2); max_op(4 * (j - 16) + 3);
+        } else if (j == 24) {
+            upd_any = false;
+            book(0);
+        } else if (j == 26) {
+            book(1);
+            resc = upd_any;
+        } else if (j == 28) {
+            if (upd_any) {                          // rare (deferred max): re-base the exponents of the rows that moved
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) ev[x][r] -= dl[x];
+            }
+        }
+    };
+    auto mask_tile = [&](const int tile) __attribute__((always_inline)) {                                      // diagonal / ragged tiles only: S = -inf beyond the row's limit
+        const int64_t k0 = (int64_t)tile * KB;
+        int64_t d64 = wpos0 - k0;                                               // wave-uniform part of the limit
+        d64 = d64 > 1000 ? 1000 : (d64 < -1000 ? -1000 : d64);
+        const int64_t e64 = Tk_ - 1 - k0;
+        const int endl = e64 > 63 ? 63 : (e64 < -1 ? -1 : (int)e64);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            int lim = lim_rel[x] + (int)d64;
+            lim = (lim > endl ? endl : lim) - 4 * half;                         // key index 32 kt + (r & 3) + 8 (r >> 2) + 4 half <= limit
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[x][kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= lim ? S[x][kt][r] : -INFINITY;
+        }
+    };
+    auto need_mask = [&](const int tile) __attribute__((always_inline)) {
+        const int64_t k0 = (int64_t)tile * KB;
+        return (k0 + KB - 1 > wpos0) || (k0 + KB > Tk_);
+    };
+
+    // ---- prologue -----------------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the Q fragment loads: the counted waits below count DMA pieces only
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[x][ks]));
+    dma_k(0); dma_v(0);
+    dma_k(1); dma_k(2);
+    dma_k(3); dma_v(1);                                    // = one trip's worth of pieces: may stay in flight
+    W_WAIT(1);
+    W_BARRIER();
+    {
+        const uint32_t kb = k_rd + 0 * W_KSTAGE;           // tile 0 -> K slot 0
+        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb, ks * 32); });
+        W_LGKM(0);
+        w_static_for<8>([&](auto jc) __attribute__((always_inline)) {
+            W_USE3(kf, qf, S);
+            constexpr int ks = decltype(jc)::v;
+            if (ks == 0) { W_MFMA_S0(S[0][0], kf[ks], qf[0][ks]); W_MFMA_S0(S[1][0], kf[ks], qf[1][ks]); }
+            else { W_MFMA_S(S[0][0], kf[ks], qf[0][ks]); W_MFMA_S(S[1][0], kf[ks], qf[1][ks]); }
+        });
+        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32); });
+        W_LGKM(0);
+        w_static_for<8>([&](auto jc) __attribute__((always_inline)) {
+            W_USE3(kf, qf, S);
+            constexpr int ks = decltype(jc)::v;
+            if (ks == 0) { W_MFMA_S0(S[0][1], kf[ks], qf[0][ks]); W_MFMA_S0(S[1][1], kf[ks], qf[1][ks]); }
+            else { W_MFMA_S(S[0][1], kf[ks], qf[0][ks]); W_MFMA_S(S[1][1], kf[ks], qf[1][ks]); }
+        });
+        W_NOP24();                                         // MFMA results -> the VALU below
+        if (need_mask(0)) mask_tile(0);
+        __builtin_amdgcn_sched_barrier(0);
+        w_static_for<32>([&](auto jc) __attribute__((always_inline)) { side(decltype(jc)::v); });
+        resc = false;                                      // (O is still zero)
+        const uint32_t kb1 = k_rd + 1 * W_KSTAGE;          // tile 1 -> K slot 1: its first-half fragments
+        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb1); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb1, ks * 32); });
+        W_LGKM(0);
+        W_BARRIER();                                       // every wave is done with K slot 0 before trip 0 refills it with tile 4
+    }
+
+    // ---- one trip per key tile: `tile` = cur (its exponents in ev), tile + 1 = nxt ---------------------------------------------------
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        if (resc) {                                        // rare (deferred max): some row moved its reference point for this tile
+            W_NOP24();
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    oacc[x][dt] = oacc[x][dt] * alpha[x];
+                    asm volatile("" : "+a"(oacc[x][dt]));
+                }
+            W_NOP24();
+        }
+        const w_srd_t ksrd = tile_srd(kp, kst_b, tile + 4), vsrd = tile_srd(vp, vst_b, tile + 2);
+        const uint32_t kslot = W_KSLOT(tile + 4), vslot = W_VSLOT(tile + 2);
+
+        // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | first V^T fragments } -----------
+        const uint32_t kb = k_rd + (uint32_t)((tile + 1) & (W_NK - 1)) * W_KSTAGE;
+        const uint32_t vo = (uint32_t)(tile % W_NV) * W_VSTAGE;
+        uint32_t vb[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vb[dt] = v_rd[dt] + vo;
+        w_u32x2 va[W_VD + 1], vc[W_VD + 1];
+        w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
+            W_USE3(kf, qf, S); W_USE3(kb, va, vc); W_USE2(vb, ev);
+            constexpr int i = decltype(ic)::v;
+            constexpr int kt = i >> 4, ks = (i >> 1) & 7, x = i & 1;
+            if (kt == 1 && x == 0) W_LGKM(w_wait_k1(ks));
+            if (ks == 0) W_MFMA_S0(S[x][kt], kf[ks], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[ks], qf[x][ks]);
+            if (x == 1 && kt == 0) W_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
+            if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragment pairs of P.V(tile)
+                constexpr int p = (i - (32 - 2 * W_VD)) >> 1;
+                W_DSR_TR(va[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256));
+                W_DSR_TR(vc[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256) + 2 * (4 * 256));
+            }
+            // five instructions of the exp stream per gap (160 = 32 x 5)
+            exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
+            exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
+        }
+        if (need_mask(tile + 1)) {
+            W_NOP24();
+            mask_tile(tile + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- phase 2: 32 x { P.V(tile) MFMA | V^T fragment reads | side stream on S | first-half K(tile+2) | DMA pieces } ---------------
+        const uint32_t kb2 = k_rd + (uint32_t)((tile + 2) & (W_NK - 1)) * W_KSTAGE;
+        w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
+            W_USE3(kf, oacc, kb2); W_USE3(vb, va, vc); W_USE3(pk, dk_off, dv_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
+            constexpr int j = decltype(jc)::v;
+            constexpr int p = j >> 1, x = j & 1;
+            constexpr int g = p >> 2, dt = p & 3;
+            constexpr bool dma = (j % 3) == 1 && j < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
+            constexpr int pc = j / 3;
+            if (dma) {
+                if (pc < 4) W_M0(kslot, pc);
+                else if (pc == 4) { if (wave == 0) W_M0(kslot, pc); }
+                else W_M0(vslot, pc - 5);
+            }
+            if (x == 0) W_LGKM(w_wait_v(p));
+            w_u32x4 pf, vf;
+            pf.x = pk[x][4 * g]; pf.y = pk[x][4 * g + 1]; pf.z = pk[x][4 * g + 2]; pf.w = pk[x][4 * g + 3];
+            vf.x = va[p % (W_VD + 1)].x; vf.y = va[p % (W_VD + 1)].y; vf.z = vc[p % (W_VD + 1)].x; vf.w = vc[p % (W_VD + 1)].y;
+            W_MFMA_O(oacc[x][dt], vf, pf);
+            if (x == 0 && p + W_VD < 16) {
+                constexpr int pp = p + W_VD;
+                W_DSR_TR(va[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256));
+                W_DSR_TR(vc[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256) + 2 * (4 * 256));
+            }
+            if (x == 0 && j >= 8 && j <= 22) W_DSR_K(kf[(j - 8) >> 1], kb2, ((j - 8) >> 1) * 32);
+            side(j);
+            if (dma) {
+                if (pc < 4) W_LD_K(ksrd, pc);
+                else if (pc == 4) { if (wave == 0) W_LD_K(ksrd, pc); }
+                else W_LD_V(vsrd, pc - 5);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // tile+1's V and tile+3's K must have landed before the next trip (this trip's pieces may stay in flight); every LDS read of
+        // this trip has returned (the K fragments of the next trip's first MFMAs among them)
+        W_LGKM(0);
+        W_WAIT(1);
+        W_BARRIER();
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (empty) DMA pieces: nothing may land after exit
+    W_NOP24();
+    // ---- epilogue: normalise; the two halves of a row trade 8-byte pieces so that every lane stores 16 contiguous bytes -------------------
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const float l_tot = w_xor32_add(l_run[x]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        const bool ok = x == 0 ? row_ok0 : row_ok1;
+        uint16_t* orow = a.o + ((int64_t)(bat * a.Tq + (x == 0 ? orow_first : orow_second)) * a.H + head) * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x16_t ov = oacc[x][dt];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ga = 2 * i, gb = 2 * i + 1;
+                const uint32_t ax = pack_bf2(ov[4 * ga] * inv, ov[4 * ga + 1] * inv);
+                const uint32_t ay = pack_bf2(ov[4 * ga + 2] * inv, ov[4 * ga + 3] * inv);
+                const uint32_t bx = pack_bf2(ov[4 * gb] * inv, ov[4 * gb + 1] * inv);
+                const uint32_t by = pack_bf2(ov[4 * gb + 2] * inv, ov[4 * gb + 3] * inv);
+                // swap(A, B): A's upper lanes <-> B's lower lanes.  Afterwards lanes 0-31 hold group 2i (d 0-3 | d 4-7), lanes 32-63 group 2i+1.
+                auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                uint4 w;
+                w.x = sx[0]; w.y = sy[0]; w.z = sx[1]; w.w = sy[1];
+                if (ok) *(uint4*)(orow + 32 * dt + 8 * (2 * i + half)) = w;
+            }
+        }
+    }
+}
+
+// Host side: geometry + launch (called by evo_attn_fwd_causal_bf16 in csrc/attn.hip for query ranges longer than one 128-row block).
+int evo_attn_w64_launch(AttnArgs a, int64_t B, void* stream) {
+    a.nbh = (int)(B * a.H);
+    a.n_qblocks = (int)((a.Tq + W_QB - 1) / W_QB);
+    a.q_pad = (int)((int64_t)a.n_qblocks * W_QB - a.Tq);
+    const int64_t n_wg = (int64_t)a.n_qblocks * a.nbh;
+    if (n_wg > 0x7fffffff) return -1;
+    hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    return evo_launch_status();
+}

@@ -13,8 +13,9 @@ What is compared with what (reference path: /root/reference/evo/scoring.py:80-84
  (b) prefix check at bench length: rows of the 8 x 8,193 HIP run (BASELINE configs[1]) vs the fp32 oracle on the
      first 2,049 tokens of the same row -- causality makes them comparable.
  (c) full-size operator checks against GPU restatements in fp64 (TEST INFRASTRUCTURE, rocFFT / eager matmul):
-     the Hyena operator vs an FFT long convolution at 8 x 8,193 x 4096 and 1 x 131,073 x 4096, and causal
-     attention vs eager softmax attention at H = 32, T = 8,193.
+     the SHIPPED Hyena operator kernels (hyena_ct on z^T in its tail and padded forms, hyena_cs on a group-major shard with
+     halo + carried state, and the modal three-launch path) vs an FFT long convolution at 8 x 8,193 x 4096,
+     1 x 131,073 x 4096 and 8 x 16,385 x 4096, and causal attention vs eager softmax attention at H = 32, T = 8,193 / 131,073.
 """
 import math
 import os
@@ -261,16 +262,21 @@ def _hyena_inputs(B, T, seed):
     return z, (fir_w, fir_b, poles, res, dskip, H)
 
 
-def _check_hyena_fullsize(B, T, seed, state_tol):
-    """Both operator forms against the SAME fp64 restatement: the three-launch modal path (cached prefill, masks) and the
-    single-pass matrix-core kernel (`hyena_mfma_kernel`, the default of every scoring forward and the kernel bench.py's
-    `roofline` reports).  Beside the fp64 truth the restatement is evaluated once more with a bf16 rounding wherever the
-    reference's eager bf16 pipeline rounds (`ref_rounding`): the engine must be no further from fp64 than that."""
+def _check_hyena_fullsize(B, T, seed, state_tol, form):
+    """The operator kernels the PRODUCT launches at this shape, each against the SAME fp64 restatement (rocFFT long convolution,
+    tests/gpu_ref64.py): `hyena_ct_kernel` on channel-major z^T (csrc/hyena_ct.hip via the C-ABI entry evo_hyena_ct: the default of every
+    scoring forward and of cached prefill, the kernel bench.py's `roofline` reports) in the form of z^T named by `form` ("tail": T = 512 k + r,
+    the bench shapes; "padded": every other T), and the three-launch modal path (evo_hyena_seg_state / carry_scan / apply: padding masks,
+    inputs shorter than 32 tokens).  Pad and tail-block positions of z^T are filled with NaN: they must not reach any output.
+    Beside the fp64 truth the restatement is evaluated once more with a bf16 rounding wherever the reference's eager bf16 pipeline rounds
+    (`ref_rounding`): the engine must be no further from fp64 than that.  [REF evo-1-131k-base_inference.yml:33,37: use_flashfft False,
+    prefill_style fft -- what the reference computes here is the FFT form]"""
     from evo_amd.hyena_tables import mfma_operand_table
     from evo_amd.ops import HipOps
     ops = HipOps()
     z, prm = _hyena_inputs(B, T, seed)
     fir_w, fir_b, poles, res, dskip, H = prm
+    D = 4096
     t0 = time.time()
     ry, rst = gpu_fft_hyena(z, *prm)
     rfloor, sfloor = gpu_fft_hyena(z, *prm, ref_rounding=True)
@@ -282,37 +288,87 @@ def _check_hyena_fullsize(B, T, seed, state_tol):
           f"arithmetic sits at y rel-L2 {floor_rl2:.3e}, end-state rel {floor_srel:.2e} from fp64")
     bound = ry.abs() * 2 ** -8 + float(ry.abs().max()) * 2e-3
     table = mfma_operand_table(poles, res, dskip)
-    for path in ("modal", "mfma"):
+    Tm, Tp, Mp, r = ops.zt_layout(B, T)
+    assert (r > 0) == (form == "tail"), (form, Tm, Tp, Mp, r)               # the shape takes the form of z^T it is meant to test
+    assert ops.zt_shape_ok(B, T, 3 * D, D)                                    # ... and the model routes it to hyena_ct (sh/model.py:_hyena_ct_ok)
+    for path in ("modal", "hyena_ct"):
         if path == "modal":
             y, st = ops.hyena_prefill(z, *prm, want_state=True)
+            assert "apply" in ops.last_hyena_io
         else:
-            want_state = hasattr(ops, "hyena_mfma_state")            # (round 3: the single-pass kernel returns the end state)
-            y, st = ops.hyena_prefill(z, *prm, table=table, want_state=want_state)
-            assert "mfma" in ops.last_hyena_io, "the table= call must route to the single-pass matrix-core kernel"
+            zt = ops.zt_from_rows(z, B, T, pad_value=float("nan"))
+            yb, st = ops.hyena_ct(zt, B, T, fir_w, fir_b, table, H, want_state=True, poles=poles, y_blk=ops.yblk_empty(B * T, D, z.device))
+            y = ops.yblk_to_rows(yb, B * T).view(B, T, D)
+            del zt, yb
         yd = y.double()
         err = (yd - ry).abs()
         rl2 = ((yd - ry).norm() / ry.norm()).item()
         excess = (err - bound).max().item()
-        srel = None if st is None else ((st.to(torch.complex128) - rst).abs().max() / rst.abs().max()).item()
-        print(f"[fft cross-check {B}x{T}] {path}: y rel-L2 {rl2:.3e}, worst excess over the bf16 bound {excess:.3e}, "
-              f"end-state rel {'n/a' if srel is None else f'{srel:.2e}'}")
+        srel = ((st.to(torch.complex128) - rst).abs().max() / rst.abs().max()).item()
+        print(f"[fft cross-check {B}x{T} {form}] {path}: y rel-L2 {rl2:.3e}, worst excess over the bf16 bound {excess:.3e}, "
+              f"end-state rel {srel:.2e}")
         assert torch.isfinite(yd).all(), path
         assert (err <= bound).all(), path
         assert rl2 < 2e-3 and rl2 <= floor_rl2, (path, rl2, floor_rl2)     # one bf16 output rounding alone = 1.1e-3
-        if st is not None:
-            assert srel <= state_tol and srel <= floor_srel, (path, srel, floor_srel)
-        del yd, err
+        assert srel <= state_tol and srel <= floor_srel, (path, srel, floor_srel)
+        del yd, err, y
 
 
 def test_hyena_operator_8x8193_full_width_vs_fft():
-    """BASELINE configs[1] shape of one Hyena layer: every one of the 8 x 8,193 x 4096 outputs of both operator forms
-    vs the FFT form."""
-    _check_hyena_fullsize(8, 8193, 21, 2e-5)
+    """BASELINE configs[1] shape of one Hyena layer: every one of the 8 x 8,193 x 4096 outputs of the shipped operator
+    (hyena_ct_kernel, tail form of z^T) and of the modal path vs the FFT form."""
+    _check_hyena_fullsize(8, 8193, 21, 2e-5, "tail")
 
 
 def test_hyena_operator_1x131073_full_width_vs_fft():
-    """BASELINE configs[2] shape: T = 131,073 at all 4096 channels, |p| up to 0.99999."""
-    _check_hyena_fullsize(1, 131073, 22, 1e-4)
+    """BASELINE configs[2] shape: T = 131,073 at all 4096 channels, |p| up to 0.99999 (hyena_ct_kernel, tail form)."""
+    _check_hyena_fullsize(1, 131073, 22, 1e-4, "tail")
+
+
+def test_hyena_operator_3x5003_padded_form_full_width_vs_fft():
+    """A shape outside the tail form (T = 5,003 = 512 x 9 + 395): batch rows of z^T padded to 64 positions, NaN in the pads."""
+    _check_hyena_fullsize(3, 5003, 24, 2e-5, "padded")
+
+
+def test_hyena_cs_shard_8x16385_full_width_with_halo_and_carry_vs_fft():
+    """BASELINE configs[3]: what ONE sequence-parallel rank runs per Hyena layer -- `hyena_cs_kernel` (csrc/hyena_cs.hip, C-ABI entry
+    evo_hyena_cs_zg) on a GROUP-MAJOR shard of 8 x 16,385 tokens at D = 4096 with the two halo rows of the left neighbour and a carried-in
+    modal state (evo_amd/sp.py: stage 2 of a shard; stage 1 = the state-only walk from a zero state is checked beside it) -- every output
+    and the end state vs the fp64 FFT restatement continued from the same halo / state."""
+    from evo_amd.hyena_tables import group_permutation, mfma_operand_table
+    from evo_amd.ops import HipOps
+    ops = HipOps()
+    B, T, D = 8, 16385, 4096
+    z, prm = _hyena_inputs(B, T + 2, 25)
+    fir_w, fir_b, poles, res, dskip, H = prm
+    halo, z = z[:, :2].contiguous(), z[:, 2:].contiguous()
+    g = torch.Generator(device=DEV).manual_seed(26)
+    s0 = torch.view_as_complex((torch.randn(B, D, 8, 2, generator=g, device=DEV) * 3.0).contiguous())
+    ry, rst = gpu_fft_hyena(z, *prm, z_halo=halo, s0=s0)
+    rst0 = gpu_fft_hyena(z, *prm, z_halo=halo)[1]
+    rfloor, sfloor = gpu_fft_hyena(z, *prm, z_halo=halo, s0=s0, ref_rounding=True)
+    floor_rl2 = ((rfloor - ry).norm() / ry.norm()).item()
+    floor_srel = ((sfloor - rst).abs().max() / rst.abs().max()).item()
+    del rfloor, sfloor
+    bound = ry.abs() * 2 ** -8 + float(ry.abs().max()) * 2e-3
+    table = mfma_operand_table(poles, res, dskip)
+    perm = group_permutation(D, H, z.device)
+    zg = z[..., perm].reshape(B * T, D // 16, 48).transpose(0, 1).contiguous()         # [G, B T, 48]: linear_zg's layout
+    halo_g = halo[..., perm].contiguous()
+    del z
+    s1 = ops.hyena_cs(zg, B, T, fir_w, fir_b, table, H, z_halo=halo_g, poles=poles, state_only=True)        # stage 1: end state from zero
+    yb, st = ops.hyena_cs(zg, B, T, fir_w, fir_b, table, H, z_halo=halo_g, s0=s0, want_state=True, poles=poles,
+                          y_blk=ops.yblk_empty(B * T, D, zg.device))                                         # stage 2: seeded pass
+    yd = ops.yblk_to_rows(yb, B * T).view(B, T, D).double()
+    err = (yd - ry).abs()
+    rl2 = ((yd - ry).norm() / ry.norm()).item()
+    srel = ((st.to(torch.complex128) - rst).abs().max() / rst.abs().max()).item()
+    srel1 = ((s1.to(torch.complex128) - rst0).abs().max() / rst0.abs().max()).item()
+    print(f"[fft cross-check shard 8x16385, halo + carried state] hyena_cs: y rel-L2 {rl2:.3e} (eager-bf16 arithmetic {floor_rl2:.3e}), worst excess "
+          f"over the bf16 bound {(err - bound).max().item():.3e}, end-state rel {srel:.2e} (floor {floor_srel:.2e}), state-only walk {srel1:.2e}")
+    assert torch.isfinite(yd).all() and (err <= bound).all()
+    assert rl2 < 2e-3 and rl2 <= floor_rl2
+    assert srel <= 2e-5 and srel <= floor_srel and srel1 <= 2e-5
 
 
 def test_attention_h32_t8193_vs_eager_fp64():
