@@ -53,6 +53,7 @@
 #ifndef W_VD
 #define W_VD 4                              // V^T fragment pairs read ahead of their MFMAs
 #endif
+// measurement builds (tools/attn_ablate.sh): W_ABL_NOEXP / NOSIDE / NOLDS / NODMA / NOBAR drop one ingredient of a trip (wrong results)
 #define W_NG_EARLY 4                        // exp groups (2 x 2 scores x ... = 14 instructions each) done under the previous trip's P.V
 
 typedef int w_srd_t __attribute__((ext_vector_type(4)));
@@ -100,6 +101,15 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 // behind it, which puts it in its gap (an input does not make the recognizer pad anything; an asm OUTPUT read by the next instruction does).
 #define W_PIN(X) asm volatile("" ::"v"(X))
 #define W_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#ifdef W_ABL_NOLDS           /* in-trip fragment reads and their waits off (the prologue's stay) */
+#define W_T_DSR_K(DST, ADDR, OFF) (void)0
+#define W_T_DSR_TR(DST, ADDR, OFF) (void)0
+#define W_T_LGKM(N) (void)0
+#else
+#define W_T_DSR_K W_DSR_K
+#define W_T_DSR_TR W_DSR_TR
+#define W_T_LGKM W_LGKM
+#endif
 #define W_NOP24()                                                        \
     do {                                                                 \
         __builtin_amdgcn_sched_barrier(0);                               \
@@ -439,22 +449,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         uint32_t vb[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vb[dt] = v_rd[dt] + vo;
-        w_u32x2 va[W_VD + 1], vc[W_VD + 1];
+        w_u32x2 va[W_VD + 1] = {}, vc[W_VD + 1] = {};
         w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
             W_USE3(kf, qf, S); W_USE3(kb, va, vc); W_USE2(vb, ev);
             constexpr int i = decltype(ic)::v;
             constexpr int kt = i >> 4, ks = (i >> 1) & 7, x = i & 1;
-            if (kt == 1 && x == 0) W_LGKM(w_wait_k1(ks));
+            if (kt == 1 && x == 0) W_T_LGKM(w_wait_k1(ks));
             if (ks == 0) W_MFMA_S0(S[x][kt], kf[ks], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[ks], qf[x][ks]);
-            if (x == 1 && kt == 0) W_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
+            if (x == 1 && kt == 0) W_T_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
             if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragment pairs of P.V(tile)
                 constexpr int p = (i - (32 - 2 * W_VD)) >> 1;
-                W_DSR_TR(va[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256));
-                W_DSR_TR(vc[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256) + 2 * (4 * 256));
+                W_T_DSR_TR(va[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256));
+                W_T_DSR_TR(vc[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256) + 2 * (4 * 256));
             }
             // five instructions of the exp stream per gap (160 = 32 x 5)
+#ifndef W_ABL_NOEXP
             exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
             exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
@@ -476,35 +488,45 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             constexpr int g = p >> 2, dt = p & 3;
             constexpr bool dma = (j % 3) == 1 && j < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
             constexpr int pc = j / 3;
+#ifndef W_ABL_NODMA
             if (dma) {
                 if (pc < 4) W_M0(kslot, pc);
                 else if (pc == 4) { if (wave == 0) W_M0(kslot, pc); }
                 else W_M0(vslot, pc - 5);
             }
-            if (x == 0) W_LGKM(w_wait_v(p));
+#endif
+            if (x == 0) W_T_LGKM(w_wait_v(p));
             w_u32x4 pf, vf;
             pf.x = pk[x][4 * g]; pf.y = pk[x][4 * g + 1]; pf.z = pk[x][4 * g + 2]; pf.w = pk[x][4 * g + 3];
             vf.x = va[p % (W_VD + 1)].x; vf.y = va[p % (W_VD + 1)].y; vf.z = vc[p % (W_VD + 1)].x; vf.w = vc[p % (W_VD + 1)].y;
             W_MFMA_O(oacc[x][dt], vf, pf);
             if (x == 0 && p + W_VD < 16) {
                 constexpr int pp = p + W_VD;
-                W_DSR_TR(va[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256));
-                W_DSR_TR(vc[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256) + 2 * (4 * 256));
+                W_T_DSR_TR(va[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256));
+                W_T_DSR_TR(vc[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256) + 2 * (4 * 256));
             }
-            if (x == 0 && j >= 8 && j <= 22) W_DSR_K(kf[(j - 8) >> 1], kb2, ((j - 8) >> 1) * 32);
+            if (x == 0 && j >= 8 && j <= 22) W_T_DSR_K(kf[(j - 8) >> 1], kb2, ((j - 8) >> 1) * 32);
+#ifndef W_ABL_NOSIDE
             side(j);
+#endif
+#ifndef W_ABL_NODMA
             if (dma) {
                 if (pc < 4) W_LD_K(ksrd, pc);
                 else if (pc == 4) { if (wave == 0) W_LD_K(ksrd, pc); }
                 else W_LD_V(vsrd, pc - 5);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         // tile+1's V and tile+3's K must have landed before the next trip (this trip's pieces may stay in flight); every LDS read of
         // this trip has returned (the K fragments of the next trip's first MFMAs among them)
-        W_LGKM(0);
+        W_T_LGKM(0);
+#ifndef W_ABL_NODMA
         W_WAIT(1);
+#endif
+#ifndef W_ABL_NOBAR
         W_BARRIER();
+#endif
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (empty) DMA pieces: nothing may land after exit
