@@ -51,7 +51,7 @@
 #define W_THR 8.0f                          // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
 #endif
 #ifndef W_VD
-#define W_VD 4                              // V^T fragment pairs read ahead of their MFMAs
+#define W_VD 6                              // V^T fragment pairs read ahead of their MFMAs
 #endif
 // measurement builds (tools/attn_ablate.sh): W_ABL_NOEXP / NOSIDE / NOLDS / NODMA / NOBAR drop one ingredient of a trip (wrong results)
 #define W_NG_EARLY 4                        // exp groups (2 x 2 scores x ... = 14 instructions each) done under the previous trip's P.V
@@ -101,13 +101,19 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 // behind it, which puts it in its gap (an input does not make the recognizer pad anything; an asm OUTPUT read by the next instruction does).
 #define W_PIN(X) asm volatile("" ::"v"(X))
 #define W_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
-#ifdef W_ABL_NOLDS           /* in-trip fragment reads and their waits off (the prologue's stay) */
+#if defined(W_ABL_NOLDS) || defined(W_ABL_NOLDSK)          /* in-trip fragment reads and their waits off (the prologue's stay) */
 #define W_T_DSR_K(DST, ADDR, OFF) (void)0
-#define W_T_DSR_TR(DST, ADDR, OFF) (void)0
-#define W_T_LGKM(N) (void)0
 #else
 #define W_T_DSR_K W_DSR_K
+#endif
+#if defined(W_ABL_NOLDS) || defined(W_ABL_NOLDSV)
+#define W_T_DSR_TR(DST, ADDR, OFF) (void)0
+#else
 #define W_T_DSR_TR W_DSR_TR
+#endif
+#if defined(W_ABL_NOLDS) || defined(W_ABL_NOLGKM)
+#define W_T_LGKM(N) (void)0
+#else
 #define W_T_LGKM W_LGKM
 #endif
 #define W_NOP24()                                                        \
@@ -125,7 +131,7 @@ constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 2 : 
 constexpr int w_wait_k1(int ks) {           // before the MFMA of phase-1 gap 16 + 2 ks: LDS instructions behind the refill of gap 2 ks + 1
     int n = 0;
     for (int i = 2 * ks + 2; i < 16 + 2 * ks; ++i) n += w_p1_ops(i);
-    return n;
+    return n > 15 ? 15 : n;                 // (the counter field has 4 bits: a smaller count only waits for more)
 }
 constexpr int w_wait_v(int p) {             // before the MFMA of phase-2 gap 2 p: LDS instructions behind the read of V^T pair p
     int n = 0;
@@ -137,7 +143,7 @@ constexpr int w_wait_v(int p) {             // before the MFMA of phase-2 gap 2 
         n += (j0 >= 8 && j0 <= 22) ? 1 : 0;
         for (int j = j0 + 1; j < 2 * p; ++j) n += w_p2_ops(j);
     }
-    return n;
+    return n > 15 ? 15 : n;
 }
 static_assert(W_VD >= 1 && W_VD <= 8, "V^T read-ahead distance");
 
@@ -330,16 +336,33 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         else tmx[x] = fmaxf(tmx[x], e[31]);
         W_PIN(tmx[x]);
     };
-    auto book = [&](const int x) __attribute__((always_inline)) {
-        const float emax = w_xor32_max(tmx[x]);            // the row's largest exponent in this tile (-inf: all masked)
-        const bool first = !seen[x];
-        const bool upd = first ? (emax > -INFINITY) : (emax > W_THR);
-        dl[x] = upd ? emax : 0.f;
-        alpha[x] = first ? 0.f : __builtin_amdgcn_exp2f(-dl[x]);                // (l and O are still 0 for a row without a key); 1 exactly when it stays
-        nm[x] -= dl[x];
-        seen[x] = seen[x] || upd;
-        upd_any = upd_any || __any(upd);
-        W_PIN(alpha[x]); W_PIN(nm[x]); W_PIN(dl[x]);
+    // the rows' reference points for tile t+1, in four steps (both query blocks side by side: two independent dependency chains per step)
+    float emx[2];
+    bool updv[2];
+    auto book_a = [&]() __attribute__((always_inline)) {                        // the row's largest exponent in this tile (-inf: all masked)
+        emx[0] = w_xor32_max(tmx[0]); emx[1] = w_xor32_max(tmx[1]);
+        W_PIN(emx[0]); W_PIN(emx[1]);
+    };
+    auto book_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            updv[x] = seen[x] ? (emx[x] > W_THR) : (emx[x] > -INFINITY);       // (a row's first visible key always sets its reference point)
+            dl[x] = updv[x] ? emx[x] : 0.f;
+        }
+        W_PIN(dl[0]); W_PIN(dl[1]);
+    };
+    auto book_c = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            alpha[x] = seen[x] ? __builtin_amdgcn_exp2f(-dl[x]) : 0.f;          // 1 exactly when the row stays; (l, O are still 0 for a row without a key)
+            nm[x] -= dl[x];
+        }
+        W_PIN(alpha[0]); W_PIN(alpha[1]); W_PIN(nm[0]); W_PIN(nm[1]);
+    };
+    auto book_d = [&]() __attribute__((always_inline)) {
+        seen[0] = seen[0] || updv[0]; seen[1] = seen[1] || updv[1];
+        upd_any = __any(updv[0] || updv[1]);
+        resc = upd_any;
     };
     // side work of P.V gap j: 120 instructions spread at <= 4 per gap; the second-half score tuples (last written by the MFMAs of
     // phase-1 gaps 30 / 31) are first read in gap 8
@@ -351,12 +374,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             fma_op(1, 4 * (j - 8)); fma_op(1, 4 * (j - 8) + 1); fma_op(1, 4 * (j - 8) + 2); fma_op(1, 4 * (j - 8) + 3);
         } else if (j < 24) {                        // row max: 16 steps per query block
             max_op(4 * (j - 16)); max_op(4 * (j - 16) + 1); max_op(4 * (j - 16) + 2); max_op(4 * (j - 16) + 3);
-        } else if (j == 24) {
-            upd_any = false;
-            book(0);
-        } else if (j == 26) {
-            book(1);
-            resc = upd_any;
+        } else if (j == 24) { book_a();
+        } else if (j == 25) { book_b();
+        } else if (j == 26) { book_c();
+        } else if (j == 27) { book_d();
         } else if (j == 28) {
             if (upd_any) {                          // rare (deferred max): re-base the exponents of the rows that moved
 #pragma unroll
@@ -382,10 +403,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) S[x][kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= lim ? S[x][kt][r] : -INFINITY;
         }
     };
-    auto need_mask = [&](const int tile) __attribute__((always_inline)) {
-        const int64_t k0 = (int64_t)tile * KB;
-        return (k0 + KB - 1 > wpos0) || (k0 + KB > Tk_);
-    };
+    // a tile needs masking from the first one that reaches past the wave's first row (k0 + 63 > wpos0) or past the last key (k0 + 64 > Tk)
+    const int mask_from = (int)((wpos0 + 1) / KB) < n_full ? (int)((wpos0 + 1) / KB) : n_full;
 
     // ---- prologue -----------------------------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the Q fragment loads: the counted waits below count DMA pieces only
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             else { W_MFMA_S(S[0][1], kf[ks], qf[0][ks]); W_MFMA_S(S[1][1], kf[ks], qf[1][ks]); }
         });
         W_NOP24();                                         // MFMA results -> the VALU below
-        if (need_mask(0)) mask_tile(0);
+        if (0 >= mask_from) mask_tile(0);
         __builtin_amdgcn_sched_barrier(0);
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) { side(decltype(jc)::v); });
         resc = false;                                      // (O is still zero)
@@ -428,6 +447,26 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     }
 
     // ---- one trip per key tile: `tile` = cur (its exponents in ev), tile + 1 = nxt ---------------------------------------------------
+    // Everything a trip needs besides its data is computed UNDER the previous trip's P.V MFMAs and carried across the back edge (the
+    // first version did it at the head of the trip: ~50 scalar instructions between the barrier and the first MFMA, with no MFMA in
+    // flight -- profiles/r05_attn_w64_ablation_v1.txt: 93 ms without any softmax instruction against 67 ms for the bare MFMAs):
+    //   kb          LDS address of this lane's K fragments of tile + 1          vb[4]   ... of its V^T fragments of tile
+    //   ksrd, kslot descriptor / LDS slot of the K tile this trip fetches (tile + 4)     vsrd, vslot: the V tile (tile + 2)
+    //   mask_nxt    tile + 1 needs masking
+    uint32_t kb = k_rd + 1 * W_KSTAGE;
+    uint32_t vb[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vb[dt] = v_rd[dt];
+    w_srd_t ksrd = tile_srd(kp, kst_b, 4), vsrd = tile_srd(vp, vst_b, 2);
+    uint32_t kslot = W_KSLOT(4), vslot = W_VSLOT(2);
+    bool mask_nxt = 1 >= mask_from;
+    int v_idx = 0;                                         // tile % 3
+    uint32_t pc_off[9];                                    // LDS offset of this wave's DMA pieces inside a K / V slot
+#pragma unroll
+    for (int pc = 0; pc < 9; ++pc) pc_off[pc] = (uint32_t)(wave + 4 * (pc < 5 ? pc : pc - 5)) * 1024u;
+#define W_M0P(SLOT_LDS, PC) asm volatile("s_add_u32 m0, %0, %1" ::"s"(SLOT_LDS), "s"(pc_off[PC]) : "memory", "m0", "scc")
+#define W_PIN_S(X) asm volatile("" ::"s"(X))
+
     for (int tile = 0; tile < n_tiles; ++tile) {
         if (resc) {                                        // rare (deferred max): some row moved its reference point for this tile
             W_NOP24();
@@ -440,20 +479,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                 }
             W_NOP24();
         }
-        const w_srd_t ksrd = tile_srd(kp, kst_b, tile + 4), vsrd = tile_srd(vp, vst_b, tile + 2);
-        const uint32_t kslot = W_KSLOT(tile + 4), vslot = W_VSLOT(tile + 2);
 
-        // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | first V^T fragments } -----------
-        const uint32_t kb = k_rd + (uint32_t)((tile + 1) & (W_NK - 1)) * W_KSTAGE;
-        const uint32_t vo = (uint32_t)(tile % W_NV) * W_VSTAGE;
-        uint32_t vb[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vb[dt] = v_rd[dt] + vo;
+        // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | DMA pieces | first V^T fragments } ---
         w_u32x2 va[W_VD + 1] = {}, vc[W_VD + 1] = {};
         w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
-            W_USE3(kf, qf, S); W_USE3(kb, va, vc); W_USE2(vb, ev);
+            W_USE3(kf, qf, S); W_USE3(kb, va, vc); W_USE2(vb, ev); W_USE3(dk_off, dv_off, pc_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
             constexpr int i = decltype(ic)::v;
             constexpr int kt = i >> 4, ks = (i >> 1) & 7, x = i & 1;
+            constexpr bool dma = (i % 3) == 1 && i < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
+            constexpr int pc = i / 3;
+#ifndef W_ABL_NODMA
+            if (dma) {                                     // m0 at the head of the gap, the load at its end: the MFMA between them is the wait state
+                if (pc < 4) W_M0P(kslot, pc);
+                else if (pc == 4) { if (wave == 0) W_M0P(kslot, pc); }
+                else W_M0P(vslot, pc);
+            }
+#endif
             if (kt == 1 && x == 0) W_T_LGKM(w_wait_k1(ks));
             if (ks == 0) W_MFMA_S0(S[x][kt], kf[ks], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[ks], qf[x][ks]);
             if (x == 1 && kt == 0) W_T_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
@@ -467,34 +508,33 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
             exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
 #endif
+#ifndef W_ABL_NODMA
+            if (dma) {
+                if (pc < 4) W_LD_K(ksrd, pc);
+                else if (pc == 4) { if (wave == 0) W_LD_K(ksrd, pc); }
+                else W_LD_V(vsrd, pc - 5);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
-        }
-        if (need_mask(tile + 1)) {
+        for (int x = 0; x < 2; ++x) l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
+        if (mask_nxt) {
             W_NOP24();
             mask_tile(tile + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- phase 2: 32 x { P.V(tile) MFMA | V^T fragment reads | side stream on S | first-half K(tile+2) | DMA pieces } ---------------
-        const uint32_t kb2 = k_rd + (uint32_t)((tile + 2) & (W_NK - 1)) * W_KSTAGE;
+        // ---- phase 2: 32 x { P.V(tile) MFMA | V^T fragment reads | side stream on S | first-half K(tile+2) | the next trip's setup } ------
+        uint32_t kb2 = 0, vb_n[4] = {0, 0, 0, 0}, kslot_n = 0, vslot_n = 0;
+        int v_idx_n = 0;
+        w_srd_t ksrd_n = ksrd, vsrd_n = vsrd;
+        bool mask_nxt_n = false;
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, oacc, kb2); W_USE3(vb, va, vc); W_USE3(pk, dk_off, dv_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
+            W_USE3(kf, oacc, kb2); W_USE3(vb, va, vc); W_USE2(pk, S);
             constexpr int j = decltype(jc)::v;
             constexpr int p = j >> 1, x = j & 1;
             constexpr int g = p >> 2, dt = p & 3;
-            constexpr bool dma = (j % 3) == 1 && j < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
-            constexpr int pc = j / 3;
-#ifndef W_ABL_NODMA
-            if (dma) {
-                if (pc < 4) W_M0(kslot, pc);
-                else if (pc == 4) { if (wave == 0) W_M0(kslot, pc); }
-                else W_M0(vslot, pc - 5);
-            }
-#endif
             if (x == 0) W_T_LGKM(w_wait_v(p));
             w_u32x4 pf, vf;
             pf.x = pk[x][4 * g]; pf.y = pk[x][4 * g + 1]; pf.z = pk[x][4 * g + 2]; pf.w = pk[x][4 * g + 3];
@@ -509,15 +549,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #ifndef W_ABL_NOSIDE
             side(j);
 #endif
-#ifndef W_ABL_NODMA
-            if (dma) {
-                if (pc < 4) W_LD_K(ksrd, pc);
-                else if (pc == 4) { if (wave == 0) W_LD_K(ksrd, pc); }
-                else W_LD_V(vsrd, pc - 5);
-            }
-#endif
+            // the next trip's setup, a few scalar instructions per gap (pinned: they would otherwise collect at the head of the loop)
+            if (j == 3) { kb2 = k_rd + (uint32_t)((tile + 2) & (W_NK - 1)) * W_KSTAGE; W_PIN(kb2); }      // = the next trip's kb
+            if (j == 5) { v_idx_n = v_idx == W_NV - 1 ? 0 : v_idx + 1; W_PIN_S(v_idx_n); }
+            if (j == 7) { const uint32_t vo = (uint32_t)v_idx_n * W_VSTAGE; vb_n[0] = v_rd[0] + vo; vb_n[1] = v_rd[1] + vo; W_PIN(vb_n[0]); W_PIN(vb_n[1]); }
+            if (j == 9) { const uint32_t vo = (uint32_t)v_idx_n * W_VSTAGE; vb_n[2] = v_rd[2] + vo; vb_n[3] = v_rd[3] + vo; W_PIN(vb_n[2]); W_PIN(vb_n[3]); }
+            if (j == 11) { kslot_n = W_KSLOT(tile + 5); W_PIN_S(kslot_n); }
+            if (j == 13) { vslot_n = lds0 + W_VBASE + (uint32_t)v_idx * W_VSTAGE; W_PIN_S(vslot_n); }          // V(tile + 3) -> slot (tile + 3) % 3 = tile's own slot, free after this trip
+            if (j == 15) { ksrd_n = tile_srd(kp, kst_b, tile + 5); W_PIN_S(ksrd_n); }
+            if (j == 19) { vsrd_n = tile_srd(vp, vst_b, tile + 3); W_PIN_S(vsrd_n); }
+            if (j == 29) { mask_nxt_n = tile + 2 >= mask_from; }
             __builtin_amdgcn_sched_barrier(0);
         });
+        kb = kb2; v_idx = v_idx_n; ksrd = ksrd_n; vsrd = vsrd_n; kslot = kslot_n; vslot = vslot_n; mask_nxt = mask_nxt_n;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vb[dt] = vb_n[dt];
         // tile+1's V and tile+3's K must have landed before the next trip (this trip's pieces may stay in flight); every LDS read of
         // this trip has returned (the K fragments of the next trip's first MFMAs among them)
         W_T_LGKM(0);
