@@ -783,7 +783,7 @@ static int attn_check_strides(int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t 
 extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H,
                                         int64_t Tq, int64_t Tk, int64_t q_pos0, int64_t q_sb, int64_t q_st,
                                         int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh, int64_t v_sb,
-                                        int64_t v_st, int64_t v_sh, float softmax_scale, void* stream) {
+                                        int64_t v_st, int64_t v_sh, float softmax_scale, void* vt_ws, void* stream) {
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || q_pos0 < 0) return -1;
     if (attn_check_strides(q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh)) return -1;
     if (H > 65535 || B > 65535) return -1;
@@ -799,8 +799,8 @@ extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void
     // them on the 8-wave pipelined kernel of rounds 2-4 (A/B measurements), 0 on the 128-row kernel
     static const int form = [] { const char* e = getenv("EVO_AMD_ATTN_FORM"); return e ? atoi(e) : 2; }();
     a.nbh = (int)(B * H);
-    a.q_pad = 0;
-    if (form >= 2 && Tq > QB) return evo_attn_w64_launch(a, B, stream);
+    a.q_pad = 0; a.vt = nullptr; a.vt_row = 0;
+    if (form >= 2 && Tq > QB && vt_ws) return evo_attn_w64_launch(a, B, vt_ws, stream);
     const int use_pipe = form >= 1 && Tq > QB;
     const int qblock = use_pipe ? PQB : QB;
     a.n_qblocks = (int)((Tq + qblock - 1) / qblock);
@@ -828,7 +828,7 @@ extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v,
     a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
     a.H = (int)H;
     a.scale_log2 = softmax_scale * 1.4426950408889634f;
-    a.n_qblocks = 1; a.q_pad = 0;
+    a.n_qblocks = 1; a.q_pad = 0; a.vt = nullptr; a.vt_row = 0;
     a.dyn_pos = dyn_pos; a.part_o = part_o; a.part_ml = part_ml; a.n_splits = (int)n_splits; a.nbh = (int)(B * H);
     hipStream_t s = (hipStream_t)stream;
     // EVO_ATTN_DECODE_FORM=0 keeps the MFMA split kernel (measurement builds); default: the streaming kernel, one split per wave

@@ -25,6 +25,8 @@ struct AttnArgs {
     int n_splits;
     int nbh;                  // B * H (prefill: 1-D grid of n_qblocks * nbh workgroups)
     int q_pad;                // attn_fwd_w64_kernel: query blocks are aligned to the END of the query range; block 0 starts at row -q_pad
+    const uint16_t* vt;       // attn_fwd_w64_kernel: V^T [B][H][128][vt_row] (keys contiguous; written by attn_vt_kernel from v)
+    int64_t vt_row;           // keys per row of vt (Tk rounded up to 64)
 };
 
 // Workgroup -> (query block, head, batch) for the prefill kernel, 1-D grid.  Blocks are dispatched round-robin
@@ -51,4 +53,4 @@ __device__ __forceinline__ void attn_block_map(const AttnArgs& a, int& qb, int& 
 
 
 // csrc/attn_w64.hip: the 4-wave / 64-rows-per-wave prefill kernel (geometry + launch)
-int evo_attn_w64_launch(AttnArgs a, int64_t B, void* stream);
+int evo_attn_w64_launch(AttnArgs a, int64_t B, void* vt_ws, void* stream);

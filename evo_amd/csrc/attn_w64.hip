@@ -31,9 +31,16 @@
 //     (+6 % tiles at 8 x 8,193);
 //   * O^T leaves through v_permlane32_swap pairs as 16-byte stores (8 per 32-row block and lane instead of 16 x 8 bytes).
 //
-// LDS images: K [64 keys][272 B] (padded rows: b128 fragment reads conflict-free, per-lane base + immediates), V [64 keys][256 B]
-// with the 64-byte blocks of a row XOR-swizzled by (key & 3) on the DMA's source side (ds_read_b64_tr_b16 conflict-free) -- as in
-// attn_fwd_pipe_kernel, whose fragment address maps are reused unchanged.
+//   * V arrives TRANSPOSED.  One wave per SIMD gets a fifth of the LDS rate on 8-byte reads: the 32 ds_read_b64_tr_b16 of a trip cost
+//     16 cycles each (16.6 of 117 ms at 1 x 131,073: profiles/r05_attn_w64_ablation_v2_lds.txt), the 16 ds_read_b128 of the K side 6.
+//     A pre-pass (attn_vt_kernel: 2 bytes moved per byte of V, ~0.4 % of the attention time at 131 k) writes V^T [head][d][key], the
+//     tile's DMA lands it as [128 d][64 keys] and a V^T fragment is ONE ds_read_b128 (16 per trip).  For the 8 keys of a lane's
+//     fragment to be contiguous, the K fragments are read with bits 2 and 3 of the key index swapped (a different per-lane constant,
+//     nothing else): accumulator register r of S^T then holds key 16 (r >> 3) + 8 (lane >> 5) + (r & 7) of its 32-key half.
+//
+// LDS images: K [64 keys][272 B] (padded rows: b128 fragment reads conflict-free, per-lane base + immediates); V^T [128 d][128 B], the
+// 16-byte chunks of a row XOR-swizzled by ((d >> 1) & 7) on the DMA's source side (b128 fragment reads conflict-free, four per-lane
+// bases + immediates).
 #include <stdlib.h>
 #include <utility>
 #include "attn_common.h"
@@ -90,9 +97,14 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 //     explicit wait states (masking / rescale / epilogue paths).
 #define W_MFMA_S0(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(S) : "a"(KF), "a"(QF))
 #define W_MFMA_S(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S) : "a"(KF), "a"(QF))
-#define W_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(O) : "v"(VF), "v"(PF))
 #define W_DSR_K(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
-#define W_DSR_TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#ifdef W_V_AGPR             /* experiment: V^T fragments in AGPRs too */
+#define W_DSR_V(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
+#define W_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(O) : "a"(VF), "v"(PF))
+#else
+#define W_DSR_V(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define W_MFMA_O(O, VF, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(O) : "v"(VF), "v"(PF))
+#endif
 // (hipcc does not capture a local that a generic lambda names ONLY in asm operands: name it once outside of them)
 #define W_USE2(A, B) (void)(A), (void)(B)
 #define W_USE3(A, B, C) (void)(A), (void)(B), (void)(C)
@@ -107,9 +119,9 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 #define W_T_DSR_K W_DSR_K
 #endif
 #if defined(W_ABL_NOLDS) || defined(W_ABL_NOLDSV)
-#define W_T_DSR_TR(DST, ADDR, OFF) (void)0
+#define W_T_DSR_V(DST, ADDR, OFF) (void)0
 #else
-#define W_T_DSR_TR W_DSR_TR
+#define W_T_DSR_V W_DSR_V
 #endif
 #if defined(W_ABL_NOLDS) || defined(W_ABL_NOLGKM)
 #define W_T_LGKM(N) (void)0
@@ -124,10 +136,10 @@ __device__ __forceinline__ float w_xor32_add(float v) {
     } while (0)
 
 // LDS instructions of a trip in program order (inside a gap: [wait] MFMA, V^T pair reads, K read):
-//   phase 1, gap i:  odd i < 16: the second-half K fragment of k-step i / 2;   even i >= 32 - 2 W_VD: V^T pair (i - (32 - 2 W_VD)) / 2
-//   phase 2, gap j:  even j: V^T pair j / 2 + W_VD (while < 16);   even 8 <= j <= 22: the first-half K fragment (j - 8) / 2 of the next tile
-constexpr int w_p1_ops(int i) { return (((i & 1) && i < 16) ? 1 : 0) + ((i >= 32 - 2 * W_VD && !(i & 1)) ? 2 : 0); }
-constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 2 : 0) + ((!(j & 1) && j >= 8 && j <= 22) ? 1 : 0); }
+//   phase 1, gap i:  odd i < 16: the second-half K fragment of k-step i / 2;   even i >= 32 - 2 W_VD: V^T fragment (i - (32 - 2 W_VD)) / 2
+//   phase 2, gap j:  even j: V^T fragment j / 2 + W_VD (while < 16);   even 8 <= j <= 22: the first-half K fragment (j - 8) / 2 of the next tile
+constexpr int w_p1_ops(int i) { return (((i & 1) && i < 16) ? 1 : 0) + ((i >= 32 - 2 * W_VD && !(i & 1)) ? 1 : 0); }
+constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 1 : 0) + ((!(j & 1) && j >= 8 && j <= 22) ? 1 : 0); }
 constexpr int w_wait_k1(int ks) {           // before the MFMA of phase-1 gap 16 + 2 ks: LDS instructions behind the refill of gap 2 ks + 1
     int n = 0;
     for (int i = 2 * ks + 2; i < 16 + 2 * ks; ++i) n += w_p1_ops(i);
@@ -170,8 +182,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     const int64_t q0 = (int64_t)qblk * W_QB - a.q_pad;                  // block 0 starts q_pad rows before the range (those rows: clamped, not stored)
     const uint16_t* qp = a.q + bat * a.q_sb + head * a.q_sh;
     const unsigned char* kp = (const unsigned char*)(a.k + bat * a.k_sb + head * a.k_sh);
-    const unsigned char* vp = (const unsigned char*)(a.v + bat * a.v_sb + head * a.v_sh);
-    const int64_t kst_b = a.k_st * 2, vst_b = a.v_st * 2;
+    const int64_t kst_b = a.k_st * 2;
 
     // ---- this lane's two query rows (column l31 of the wave's two 32-row blocks) ---------------------------------------------------
     const int64_t wrow0 = q0 + wave * 64;                               // wave-uniform
@@ -211,14 +222,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         c = c < 256 ? c : 0;                                            // pad lanes re-fetch the row's first granule (never read back)
         dk_off[jj] = (uint32_t)r * (uint32_t)kst_b + (uint32_t)c;
     }
+    // V^T piece j (16 of 1 KiB) = d rows 8 j .. 8 j + 7 of the tile, 128 B (64 keys) each: lane -> row (lane >> 3), LDS chunk lane & 7, which
+    // holds the row's chunk (lane & 7) ^ ((d >> 1) & 7); d >> 1 = 4 j + (lane >> 4) and j = wave + 4 jj, so the swizzle is one per-lane
+    // constant of the wave.  The piece's row offset goes into the instruction's SGPR offset.
+    const int64_t vt_row_b = a.vt_row * 2;
     uint32_t dv_off;
     {
-        const int r = lane >> 4;
-        int c = (lane & 15) * 16;
-        c = ((((c >> 6) ^ r) & 3) << 6) | (c & 63);
-        dv_off = (uint32_t)r * (uint32_t)vst_b + (uint32_t)c;
+        const int r = lane >> 3;
+        const int f = (4 * (wave & 1) + (lane >> 4)) & 7;
+        dv_off = (uint32_t)r * (uint32_t)vt_row_b + (uint32_t)(((lane & 7) ^ f) << 4);
     }
-    const uint32_t dv_soff = (uint32_t)(4 * vst_b);                    // per V piece: 4 rows
+    const uint32_t dv_soff = (uint32_t)(8 * vt_row_b);                 // per V^T piece: 8 rows
+    const unsigned char* vtp = (const unsigned char*)(a.vt + ((int64_t)bat * a.H + head) * DH * a.vt_row);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // Buffer descriptors of one tile: base = its first row, num_records = bytes up to the end of the last VALID key (0 past the end):
     // the hardware bounds check returns zeros beyond -- no clamping, every trip issues the same instructions.  Branch-free scalar code:
@@ -232,6 +247,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         d[0] = (int)(uint32_t)a64;
         d[1] = (int)(uint32_t)(a64 >> 32);
         d[2] = (int)(tile < n_full ? rec_full : (tile == n_full ? rec_rem : 0u));
+        d[3] = 0x00020000;
+        return d;
+    };
+    // V^T tile: base = column 64 tile of the head's plane, rows vt_row_b apart; the plane is padded to whole tiles
+    const int n_vt = (int)(a.vt_row / KB);
+    auto vt_srd = [&](int tile) __attribute__((always_inline)) {
+        const uint64_t a64 = (uint64_t)vtp + (uint64_t)(uint32_t)tile * (uint64_t)(KB * 2);
+        w_srd_t d;
+        d[0] = (int)(uint32_t)a64;
+        d[1] = (int)(uint32_t)(a64 >> 32);
+        d[2] = (int)(tile < n_vt ? (uint32_t)((DH - 1) * vt_row_b + KB * 2) : 0u);
         d[3] = 0x00020000;
         return d;
     };
@@ -262,20 +288,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         for (int jj = 0; jj < 5; ++jj) W_DMA_K(s_, st_, jj);
     };
     auto dma_v = [&](int tile) __attribute__((always_inline)) {
-        const w_srd_t s_ = tile_srd(vp, vst_b, tile);
+        const w_srd_t s_ = vt_srd(tile);
         const uint32_t st_ = W_VSLOT(tile);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) W_DMA_V(s_, st_, jj);
     };
 
-    // per-lane fragment addresses inside a stage (everything else is an immediate): the maps of attn_fwd_pipe_kernel
-    const uint32_t k_rd = lds0 + (uint32_t)(l31 * W_KROW + half * 16);
+    // per-lane fragment addresses inside a stage (everything else is an immediate)
+    //   K: this lane's row of a 32-key half = l31 with bits 2 and 3 swapped (see the header: keys of a P^T fragment contiguous)
+    //   V^T: row d = l31 (+ 32 dt: immediate), chunk 2 g + half of the row (g = 16-key group), XOR (d >> 1) & 7
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const uint32_t k_rd = lds0 + (uint32_t)(krow * W_KROW + half * 16);
     uint32_t v_rd[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const int r0 = ((lane & 15) >> 2) + 4 * half;
-        v_rd[dt] = lds0 + (uint32_t)(W_VBASE + r0 * 256 + ((dt ^ (r0 & 3)) << 6) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
-    }
+    for (int g = 0; g < 4; ++g) v_rd[g] = lds0 + (uint32_t)(W_VBASE + l31 * 128 + (((2 * g + half) ^ ((l31 >> 1) & 7)) << 4));
 
     f32x16_t oacc[2][4];                          // O^T accumulators: AGPRs
 #pragma unroll
@@ -396,11 +422,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             int lim = lim_rel[x] + (int)d64;
-            lim = (lim > endl ? endl : lim) - 4 * half;                         // key index 32 kt + (r & 3) + 8 (r >> 2) + 4 half <= limit
+            lim = (lim > endl ? endl : lim) - 8 * half;                         // key index 32 kt + 16 (r >> 3) + 8 half + (r & 7) <= limit
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[x][kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= lim ? S[x][kt][r] : -INFINITY;
+                for (int r = 0; r < 16; ++r) S[x][kt][r] = (32 * kt + 16 * (r >> 3) + (r & 7)) <= lim ? S[x][kt][r] : -INFINITY;
         }
     };
     // a tile needs masking from the first one that reaches past the wave's first row (k0 + 63 > wpos0) or past the last key (k0 + 64 > Tk)
@@ -450,14 +476,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     // Everything a trip needs besides its data is computed UNDER the previous trip's P.V MFMAs and carried across the back edge (the
     // first version did it at the head of the trip: ~50 scalar instructions between the barrier and the first MFMA, with no MFMA in
     // flight -- profiles/r05_attn_w64_ablation_v1.txt: 93 ms without any softmax instruction against 67 ms for the bare MFMAs):
-    //   kb          LDS address of this lane's K fragments of tile + 1          vb[4]   ... of its V^T fragments of tile
+    //   kb          LDS address of this lane's K fragments of tile + 1          vb[4]   ... of its V^T fragments of tile (one per 16-key group)
     //   ksrd, kslot descriptor / LDS slot of the K tile this trip fetches (tile + 4)     vsrd, vslot: the V tile (tile + 2)
     //   mask_nxt    tile + 1 needs masking
     uint32_t kb = k_rd + 1 * W_KSTAGE;
     uint32_t vb[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vb[dt] = v_rd[dt];
-    w_srd_t ksrd = tile_srd(kp, kst_b, 4), vsrd = tile_srd(vp, vst_b, 2);
+    for (int g = 0; g < 4; ++g) vb[g] = v_rd[g];
+    w_srd_t ksrd = tile_srd(kp, kst_b, 4), vsrd = vt_srd(2);
     uint32_t kslot = W_KSLOT(4), vslot = W_VSLOT(2);
     bool mask_nxt = 1 >= mask_from;
     int v_idx = 0;                                         // tile % 3
@@ -481,9 +507,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         }
 
         // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | DMA pieces | first V^T fragments } ---
-        w_u32x2 va[W_VD + 1] = {}, vc[W_VD + 1] = {};
+        w_u32x4 vfr[W_VD + 1] = {};                        // V^T fragments in flight (fragment p = (16-key group p >> 2, d tile p & 3))
         w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
-            W_USE3(kf, qf, S); W_USE3(kb, va, vc); W_USE2(vb, ev); W_USE3(dk_off, dv_off, pc_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
+            W_USE3(kf, qf, S); W_USE3(kb, vfr, vb); W_USE2(ev, pk); W_USE3(dk_off, dv_off, pc_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
             constexpr int i = decltype(ic)::v;
             constexpr int kt = i >> 4, ks = (i >> 1) & 7, x = i & 1;
             constexpr bool dma = (i % 3) == 1 && i < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
@@ -498,10 +524,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             if (kt == 1 && x == 0) W_T_LGKM(w_wait_k1(ks));
             if (ks == 0) W_MFMA_S0(S[x][kt], kf[ks], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[ks], qf[x][ks]);
             if (x == 1 && kt == 0) W_T_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
-            if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragment pairs of P.V(tile)
+            if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragments of P.V(tile)
                 constexpr int p = (i - (32 - 2 * W_VD)) >> 1;
-                W_T_DSR_TR(va[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256));
-                W_T_DSR_TR(vc[p], vb[p & 3], (4 * (p >> 2)) * (4 * 256) + 2 * (4 * 256));
+#ifdef W_ABL_VADDRK
+                W_T_DSR_V(vfr[p], kb, (p & 3) * 32);
+#else
+                W_T_DSR_V(vfr[p], vb[p >> 2], (p & 3) * 4096);
+#endif
             }
             // five instructions of the exp stream per gap (160 = 32 x 5)
 #ifndef W_ABL_NOEXP
@@ -531,19 +560,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         w_srd_t ksrd_n = ksrd, vsrd_n = vsrd;
         bool mask_nxt_n = false;
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, oacc, kb2); W_USE3(vb, va, vc); W_USE2(pk, S);
+            W_USE3(kf, oacc, kb2); W_USE3(vb, vfr, pk); W_USE2(S, ev);
             constexpr int j = decltype(jc)::v;
             constexpr int p = j >> 1, x = j & 1;
             constexpr int g = p >> 2, dt = p & 3;
             if (x == 0) W_T_LGKM(w_wait_v(p));
-            w_u32x4 pf, vf;
+            w_u32x4 pf;
             pf.x = pk[x][4 * g]; pf.y = pk[x][4 * g + 1]; pf.z = pk[x][4 * g + 2]; pf.w = pk[x][4 * g + 3];
-            vf.x = va[p % (W_VD + 1)].x; vf.y = va[p % (W_VD + 1)].y; vf.z = vc[p % (W_VD + 1)].x; vf.w = vc[p % (W_VD + 1)].y;
-            W_MFMA_O(oacc[x][dt], vf, pf);
+            W_MFMA_O(oacc[x][dt], vfr[p % (W_VD + 1)], pf);
             if (x == 0 && p + W_VD < 16) {
                 constexpr int pp = p + W_VD;
-                W_T_DSR_TR(va[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256));
-                W_T_DSR_TR(vc[pp % (W_VD + 1)], vb[pp & 3], (4 * (pp >> 2)) * (4 * 256) + 2 * (4 * 256));
+#ifdef W_ABL_VADDRK
+                W_T_DSR_V(vfr[pp % (W_VD + 1)], kb2, (pp & 3) * 32);
+#else
+                W_T_DSR_V(vfr[pp % (W_VD + 1)], vb[pp >> 2], (pp & 3) * 4096);
+#endif
             }
             if (x == 0 && j >= 8 && j <= 22) W_T_DSR_K(kf[(j - 8) >> 1], kb2, ((j - 8) >> 1) * 32);
 #ifndef W_ABL_NOSIDE
@@ -557,13 +588,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             if (j == 11) { kslot_n = W_KSLOT(tile + 5); W_PIN_S(kslot_n); }
             if (j == 13) { vslot_n = lds0 + W_VBASE + (uint32_t)v_idx * W_VSTAGE; W_PIN_S(vslot_n); }          // V(tile + 3) -> slot (tile + 3) % 3 = tile's own slot, free after this trip
             if (j == 15) { ksrd_n = tile_srd(kp, kst_b, tile + 5); W_PIN_S(ksrd_n); }
-            if (j == 19) { vsrd_n = tile_srd(vp, vst_b, tile + 3); W_PIN_S(vsrd_n); }
+            if (j == 19) { vsrd_n = vt_srd(tile + 3); W_PIN_S(vsrd_n); }
             if (j == 29) { mask_nxt_n = tile + 2 >= mask_from; }
             __builtin_amdgcn_sched_barrier(0);
         });
         kb = kb2; v_idx = v_idx_n; ksrd = ksrd_n; vsrd = vsrd_n; kslot = kslot_n; vslot = vslot_n; mask_nxt = mask_nxt_n;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vb[dt] = vb_n[dt];
+        for (int g = 0; g < 4; ++g) vb[g] = vb_n[g];
         // tile+1's V and tile+3's K must have landed before the next trip (this trip's pieces may stay in flight); every LDS read of
         // this trip has returned (the K fragments of the next trip's first MFMAs among them)
         W_T_LGKM(0);
@@ -605,13 +636,47 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     }
 }
 
-// Host side: geometry + launch (called by evo_attn_fwd_causal_bf16 in csrc/attn.hip for query ranges longer than one 128-row block).
-int evo_attn_w64_launch(AttnArgs a, int64_t B, void* stream) {
+// V [B, Tk, H, 128] (strided rows) -> V^T [B][H][128][vt_row] (vt_row = Tk rounded up to 64, the pad keys zero): one workgroup per
+// (64-key tile, head, batch row).  Whole 256-byte rows in (16 lanes each), whole 128-byte row pieces out (8 lanes each); the tile
+// turns in LDS ([64 keys][130] halves: both sides conflict-free).  2 bytes moved per byte of V.
+__global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int64_t Tk, int64_t v_sb,
+                                                      int64_t v_st, int64_t v_sh, int64_t vt_row, int H) {
+    __shared__ uint16_t tile[KB][DH + 2];
+    const int tid = threadIdx.x, head = blockIdx.y, bat = blockIdx.z;
+    const int64_t k0 = (int64_t)blockIdx.x * KB;
+    const uint16_t* vp = v + bat * v_sb + head * v_sh;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int key = (tid >> 4) + 16 * ps, ch = tid & 15;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 + key < Tk) w = *(const uint4*)(vp + (k0 + key) * v_st + 8 * ch);
+        uint32_t* dst = (uint32_t*)&tile[key][8 * ch];           // (row pitch 260 B: 4-byte aligned)
+        dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+    }
+    __syncthreads();
+    uint16_t* op = vt + (((int64_t)bat * H + head) * DH) * vt_row + k0;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int d = (tid >> 3) + 32 * ps, c = tid & 7;          // 8 lanes = one 128-byte piece of row d
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)tile[8 * c + 2 * i][d] | ((uint32_t)tile[8 * c + 2 * i + 1][d] << 16);
+        *(uint4*)(op + (int64_t)d * vt_row + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Host side: geometry + launches (called by evo_attn_fwd_causal_bf16 in csrc/attn.hip for query ranges longer than one 128-row block).
+// vt_ws: B * H * 128 * (Tk rounded up to 64) bf16 of workspace for V^T (include/evo_mi355x.h).
+int evo_attn_w64_launch(AttnArgs a, int64_t B, void* vt_ws, void* stream) {
     a.nbh = (int)(B * a.H);
     a.n_qblocks = (int)((a.Tq + W_QB - 1) / W_QB);
     a.q_pad = (int)((int64_t)a.n_qblocks * W_QB - a.Tq);
+    a.vt = (const uint16_t*)vt_ws;
+    a.vt_row = (a.Tk + KB - 1) / KB * KB;
     const int64_t n_wg = (int64_t)a.n_qblocks * a.nbh;
-    if (n_wg > 0x7fffffff) return -1;
+    if (n_wg > 0x7fffffff || a.vt_row / KB > 0x7fffffff || DH * a.vt_row * 2 > 0xffffffffll) return -1;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3((unsigned)(a.vt_row / KB), (unsigned)a.H, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       a.v, (uint16_t*)vt_ws, a.Tk, a.v_sb, a.v_st, a.v_sh, a.vt_row, a.H);
     hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }

@@ -32,7 +32,7 @@ _SIGNATURES = {
     "evo_hyena_apply": ([_PTR] * 10 + [_I64] * 5 + [_PTR], _c.c_int),
     "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
-    "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR], _c.c_int),
+    "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR, _PTR], _c.c_int),
     "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
@@ -57,7 +57,7 @@ _SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 7          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 8          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -171,6 +171,8 @@ class HipOps:
         # Routing (round 4): every prefill dense layer runs on the hand-written persistent kernel of csrc/gemm.hip -- no vendor GEMM in
         # a scoring step.  The attributes below are in-process A/B knobs for bench.py's legs and the tests (no environment switches):
         self.attn_gemm_mfma = True
+        # prefill attention on the 64-rows-per-wave kernel of round 5 (csrc/attn_w64.hip); False: the 8-wave kernel of rounds 2-4 (bench A/B leg)
+        self.attn_w64 = True
         # all_gemm_mfma = False puts the plain dense layers (l3, the unembedding of model(ids)) back on hipBLASLt through torch.addmm:
         # the library is 1-3 % faster on l3's shape (K = 11,008; profiles/r03_gemm_notes.txt) -- bench.py times that leg beside the headline
         self.all_gemm_mfma = True
@@ -870,11 +872,13 @@ class HipOps:
         if hd != 128:
             raise RuntimeError("attention: head dim must be 128")
         o = torch.empty(B, Tq, H, hd, dtype=torch.bfloat16, device=q.device)
+        # query ranges longer than one 128-row block: the 64-rows-per-wave kernel, which reads V^T from a workspace its pre-pass fills
+        vt = torch.empty(B, H, hd, (Tk + 63) // 64 * 64, dtype=torch.bfloat16, device=q.device) if (Tq > 128 and self.attn_w64) else None
         with self._t("attn_fwd"):
             _check(self.lib.evo_attn_fwd_causal_bf16(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
                 q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _stream()), "evo_attn_fwd_causal_bf16")
+                v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _ptr(vt), _stream()), "evo_attn_fwd_causal_bf16")
         return o
 
     def attention_decode(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,

@@ -34,8 +34,10 @@ extern "C" {
  *   6: evo_hyena_cs_zg (the single-pass operator with channel-stationary waves: outputs, end state or state-only walk; blocked y)
  *      and evo_linear_xblk_mfma_bf16 (the output projection on that blocked y) added.
  *   7: evo_hyena_ct (the same operator on channel-major z^T: no input window in LDS), evo_linear_t_mfma_bf16 (the projection with
- *      a transposed result) and evo_rmsnorm_rows_bf16 (RMSNorm with padded batch rows) added. */
-#define EVO_ABI_VERSION 7
+ *      a transposed result) and evo_rmsnorm_rows_bf16 (RMSNorm with padded batch rows) added.
+ *   8: evo_attn_fwd_causal_bf16 gained `vt_ws` (workspace for V^T: the round-5 prefill kernel of csrc/attn_w64.hip reads its V
+ *      fragments from a transposed copy). */
+#define EVO_ABI_VERSION 8
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -215,13 +217,16 @@ int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const f
  * MFMA 32x32x16 bf16 tiles, online softmax in fp32, head dim 128 only.
  *   q [B, Tq, H, 128], k/v [B, Tk, H, 128] bf16 with explicit element strides (batch, token, head);
  *   o [B, Tq, H, 128] bf16 contiguous.  Query i may see key j iff j <= i + q_pos0 (q_pos0 = absolute
- *   position of query 0 minus absolute position of key 0). */
+ *   position of query 0 minus absolute position of key 0).
+ *   vt_ws: caller-owned workspace of B * H * 128 * (Tk rounded up to 64) bf16, or NULL.  Query ranges longer than 128 rows run
+ *   the 64-rows-per-wave kernel (csrc/attn_w64.hip: one wave per SIMD, K / V tiles through LDS-DMA rings), which reads V^T:
+ *   a pre-pass launch writes it into vt_ws.  With vt_ws == NULL (or Tq <= 128) the kernels of rounds 1-4 run (csrc/attn.hip). */
 int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o,
                              int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t q_pos0,
                              int64_t q_sb, int64_t q_st, int64_t q_sh,
                              int64_t k_sb, int64_t k_st, int64_t k_sh,
                              int64_t v_sb, int64_t v_st, int64_t v_sh,
-                             float softmax_scale, void* stream);
+                             float softmax_scale, void* vt_ws, void* stream);
 
 /* decode form (one query per sequence, Tq = 1): split-K over the key range ("flash-decoding") + combine.
  * replaces flash_attn_with_kvcache                           [REF evo/generation.py:109-110,138-155]

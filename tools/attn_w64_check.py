@@ -22,9 +22,10 @@ if os.path.exists(p0):
 def attn(l, q, k, v, off):
     B, Tq, H, hd = q.shape
     o = torch.empty(B, Tq, H, hd, dtype=torch.bfloat16, device=q.device)
+    vt = torch.full((B, H, hd, (k.shape[1] + 63) // 64 * 64), float("nan"), dtype=torch.bfloat16, device=q.device)      # (poisoned workspace)
     rc = l.evo_attn_fwd_causal_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, k.shape[1], int(off),
                                     q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                                    v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), torch.cuda.current_stream().cuda_stream)
+                                    v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), vt.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
     return o
 
