@@ -58,9 +58,12 @@
 #define W_THR 8.0f                          // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
 #endif
 #ifndef W_VD
-#define W_VD 6                              // V^T fragment pairs read ahead of their MFMAs
+#define W_VD 4                              // V^T fragments read ahead of their MFMAs (5+: the register file spills into AGPR copies)
 #endif
 // measurement builds (tools/attn_ablate.sh): W_ABL_NOEXP / NOSIDE / NOLDS / NODMA / NOBAR drop one ingredient of a trip (wrong results)
+#ifndef W_LSUM_MFMA
+#define W_LSUM_MFMA 0                       // 1: softmax denominators on the matrix pipe (8 more MFMAs per trip instead of 64 v_add_f32: measured 4 % SLOWER -- an MFMA costs its 32 pipe cycles, an add ~2.7)
+#endif
 #define W_NG_EARLY 4                        // exp groups (2 x 2 scores x ... = 14 instructions each) done under the previous trip's P.V
 
 typedef int w_srd_t __attribute__((ext_vector_type(4)));
@@ -97,6 +100,7 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 //     explicit wait states (masking / rescale / epilogue paths).
 #define W_MFMA_S0(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(S) : "a"(KF), "a"(QF))
 #define W_MFMA_S(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S) : "a"(KF), "a"(QF))
+#define W_MFMA_L(L, ONES, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(L) : "v"(ONES), "v"(PF))
 #define W_DSR_K(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
 #ifdef W_V_AGPR             /* experiment: V^T fragments in AGPRs too */
 #define W_DSR_V(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
@@ -135,24 +139,28 @@ __device__ __forceinline__ float w_xor32_add(float v) {
         __builtin_amdgcn_sched_barrier(0);                               \
     } while (0)
 
-// LDS instructions of a trip in program order (inside a gap: [wait] MFMA, V^T pair reads, K read):
-//   phase 1, gap i:  odd i < 16: the second-half K fragment of k-step i / 2;   even i >= 32 - 2 W_VD: V^T fragment (i - (32 - 2 W_VD)) / 2
-//   phase 2, gap j:  even j: V^T fragment j / 2 + W_VD (while < 16);   even 8 <= j <= 22: the first-half K fragment (j - 8) / 2 of the next tile
-constexpr int w_p1_ops(int i) { return (((i & 1) && i < 16) ? 1 : 0) + ((i >= 32 - 2 * W_VD && !(i & 1)) ? 1 : 0); }
-constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 1 : 0) + ((!(j & 1) && j >= 8 && j <= 22) ? 1 : 0); }
-constexpr int w_wait_k1(int ks) {           // before the MFMA of phase-1 gap 16 + 2 ks: LDS instructions behind the refill of gap 2 ks + 1
+// LDS instructions of a trip in program order (inside a gap: [wait] MFMA, V^T fragment read, K fragment read).  The 16 K fragments of a
+// tile (f = 8 kt + ks, consumed by the QK^T MFMAs of phase-1 gaps 2 f, 2 f + 1) go through a ring of FOUR registers quads: fragment f >= 4
+// is read right behind the second MFMA of fragment f - 4 (gap 2 f - 7), fragments 0..3 of the NEXT tile under the P.V MFMAs.
+//   phase 1, gap i:  odd i <= 23: K fragment (i + 7) / 2;                      even i >= 32 - 2 W_VD: V^T fragment (i - (32 - 2 W_VD)) / 2
+//   phase 2, gap j:  even j: V^T fragment j / 2 + W_VD (while < 16);           j = 10, 14, 18, 22: K fragment (j - 10) / 4 of the next tile
+constexpr int w_p1_ops(int i) { return (((i & 1) && i <= 23) ? 1 : 0) + ((i >= 32 - 2 * W_VD && !(i & 1)) ? 1 : 0); }
+constexpr int w_p2_ops(int j) { return ((!(j & 1) && (j / 2 + W_VD) < 16) ? 1 : 0) + ((j >= 10 && j <= 22 && ((j - 10) & 3) == 0) ? 1 : 0); }
+constexpr int w_wait_k1(int f) {            // before the MFMA of phase-1 gap 2 f (f >= 4): LDS instructions behind the read of gap 2 f - 7
     int n = 0;
-    for (int i = 2 * ks + 2; i < 16 + 2 * ks; ++i) n += w_p1_ops(i);
+    for (int i = 2 * f - 6; i < 2 * f; ++i) n += w_p1_ops(i);
     return n > 15 ? 15 : n;                 // (the counter field has 4 bits: a smaller count only waits for more)
 }
-constexpr int w_wait_v(int p) {             // before the MFMA of phase-2 gap 2 p: LDS instructions behind the read of V^T pair p
+constexpr int w_wait_v(int p) {             // before the MFMA of phase-2 gap 2 p: LDS instructions behind the read of V^T fragment p
     int n = 0;
     if (p < W_VD) {
-        for (int i = 32 - 2 * W_VD + 2 * p + 1; i < 32; ++i) n += w_p1_ops(i);
+        const int i0 = 32 - 2 * W_VD + 2 * p;
+        n += ((i0 & 1) && i0 <= 23) ? 1 : 0;                                   // (a K read in the same gap comes after the V^T read)
+        for (int i = i0 + 1; i < 32; ++i) n += w_p1_ops(i);
         for (int j = 0; j < 2 * p; ++j) n += w_p2_ops(j);
     } else {
         const int j0 = 2 * (p - W_VD);
-        n += (j0 >= 8 && j0 <= 22) ? 1 : 0;
+        n += (j0 >= 10 && j0 <= 22 && ((j0 - 10) & 3) == 0) ? 1 : 0;
         for (int j = j0 + 1; j < 2 * p; ++j) n += w_p2_ops(j);
     }
     return n > 15 ? 15 : n;
@@ -187,15 +195,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     // ---- this lane's two query rows (column l31 of the wave's two 32-row blocks) ---------------------------------------------------
     const int64_t wrow0 = q0 + wave * 64;                               // wave-uniform
     int64_t qrow[2];
-    w_u32x4 qf[2][8];                                                   // Q fragments: AGPRs from here on (only ever "a" operands)
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        qrow[x] = wrow0 + 32 * x + l31;
-        const int64_t qc = qrow[x] < 0 ? 0 : qrow[x];                   // (rows past the end cannot occur: blocks end at Tq)
-        const w_u32x4* qr = (const w_u32x4*)(qp + qc * a.q_st);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[x][ks] = qr[2 * ks + half];
-    }
+    for (int x = 0; x < 2; ++x) qrow[x] = wrow0 + 32 * x + l31;
     // key limit of a lane's row relative to the wave's first (clamped) row position; the mask path adds the wave-uniform part
     const int64_t wpos0 = (wrow0 < 0 ? 0 : wrow0) + q_pos0_;           // position of the wave's first valid row: min over the wave
     int lim_rel[2];
@@ -316,33 +317,67 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     // domain) that moves only when a tile's largest exponent exceeds W_THR (or at the row's first visible key); `seen` = it has one.
     float nm[2] = {0.f, 0.f};                     // -(reference point); 0 until the row has seen a key
     bool seen[2] = {false, false};
-    float l_run[2] = {0.f, 0.f};                  // this lane's share of the row's denominator
-    float alpha[2] = {1.f, 1.f};                  // factor the pending tile applies to l (and to O when `resc`)
-    float psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
+    float alpha[2] = {1.f, 1.f};                  // factor the pending tile applies to O and l when `resc`
+    // The softmax denominators ride on the matrix pipe: l^T[.][q] = ones . P^T, one more MFMA per 16-key group and query block (8 of
+    // 72 per trip) with an all-ones A fragment.  Every row of the 32 x 32 result holds the column sums of the bf16 P the numerator
+    // uses.  The wave is bound by instruction ISSUE, not by the pipe (profiles/r05_attn_w64_cycles_by_ablation.txt): 8 MFMA issues
+    // replace 64 v_add_f32 (+ the running-sum bookkeeping).
+    f32x16_t lacc[2];                             // AGPRs
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[x][r] = 0.f;
+        asm volatile("" : "+a"(lacc[x]));
+    }
+    const w_u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#if !W_LSUM_MFMA
+    float l_run[2] = {0.f, 0.f}, psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
+#endif
     bool resc = false;                            // wave-uniform: some row of the wave moved its reference point for the pending tile
     const float c_sc = a.scale_log2;
 
     f32x16_t S[2][2];                             // score tile of the NEXT tile [query block][32-key half]: VGPRs, MFMA outputs only
     float ev[2][32];                              // its exponents s c - reference, then (next trip) the current tile's: [x][16 kt + r]
     uint32_t pk[2][16];                           // bf16-packed P^T of the current tile [query block][4 * (16-key group) + word]
-    w_u32x4 kf[8];                                // K fragments (one 32-key half, 8 k-steps): AGPRs
+    w_u32x4 kf[4];                                // K fragments: a ring of four (see w_p1_ops): AGPRs
 
-    // ---- phase-1 stream: P = 2^e, row sums, bf16 pack -- 160 instructions, in the order P.V consumes the words ------------------------
+    // ---- phase-1 stream: P = 2^e and the bf16 pack -- 96 instructions, in the order P.V consumes the words ---------------------------
     // unit u: 16-key group g = u >> 3, query block x = (u >> 2) & 1, word w = u & 3 (two scores);  group G = units 2G, 2G+1:
-    // 10 instructions: 4 x exp2, 4 x add, 2 x pack
+    // 6 instructions: 4 x exp2, 2 x pack
     float tp[4];
+#if W_LSUM_MFMA
+    auto exp_op = [&](const int G, const int o) __attribute__((always_inline)) {
+        const int which = o < 4 ? (o >> 1) : (o - 4);
+        const int u = 2 * G + which;
+        const int g = u >> 3, x = (u >> 2) & 1, w = u & 3;
+        const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;                     // index into ev[x]: 16 kt + register of the MFMA tile
+#ifdef W_ABL_EXPMUL
+        if (o < 4) { tp[o] = ev[x][r + (o & 1)] * c_sc; W_PIN(tp[o]); }
+#else
+        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(ev[x][r + (o & 1)]); W_PIN(tp[o]); }
+#endif
+        else { pk[x][4 * g + w] = pack_bf2(tp[2 * which], tp[2 * which + 1]); W_PIN(pk[x][4 * g + w]); }
+    };
+
+#else
+    // (the form with the row sums in the VALU stream: 10 instructions per group -- 4 x exp2, 4 x add, 2 x pack; 160 per trip)
     auto exp_op = [&](const int G, const int o) __attribute__((always_inline)) {
         const int which = o < 8 ? ((o & 3) >> 1) : (o - 8);
         const int u = 2 * G + which;
         const int g = u >> 3, x = (u >> 2) & 1, w = u & 3;
-        const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;                     // index into ev[x]: 16 kt + register of the MFMA tile
+        const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;
+#ifdef W_ABL_EXPMUL
+        if (o < 4) { tp[o] = ev[x][r + (o & 1)] * c_sc; W_PIN(tp[o]); }
+#else
         if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(ev[x][r + (o & 1)]); W_PIN(tp[o]); }
+#endif
         else if (o < 8) {
-            const bool first_of_row = (u & 3) == 0 && g == 0 && which == 0;          // the tile's first unit of this query block
+            const bool first_of_row = w == 0 && g == 0;
             if ((o & 1) == 0) { psa[x] = first_of_row ? tp[o - 4] : psa[x] + tp[o - 4]; W_PIN(psa[x]); }
             else { psb[x] = first_of_row ? tp[o - 4] : psb[x] + tp[o - 4]; W_PIN(psb[x]); }
         } else { pk[x][4 * g + w] = pack_bf2(tp[2 * which], tp[2 * which + 1]); W_PIN(pk[x][4 * g + w]); }
     };
+#endif
 
     // ---- phase-2 side stream on the NEXT tile's scores: exponents, row max, the reference-point bookkeeping --------------------------
     // every instruction is the compiler's own (it pads its hazards; fmaxf of FMA results needs no canonicalising v_max; the file is
@@ -433,41 +468,45 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     const int mask_from = (int)((wpos0 + 1) / KB) < n_full ? (int)((wpos0 + 1) / KB) : n_full;
 
     // ---- prologue -----------------------------------------------------------------------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the Q fragment loads: the counted waits below count DMA pieces only
+    // the first tiles' DMA goes out BEFORE the Q fragment loads (one memory latency per workgroup instead of two); the compiler's own
+    // wait for those loads then also covers the (older) DMA pieces
+    dma_k(0); dma_v(0);
+    dma_k(1); dma_k(2);
+    dma_k(3); dma_v(1);
+    w_u32x4 qf[2][8];                                                   // Q fragments: AGPRs from here on (only ever "a" operands)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int64_t qc = qrow[x] < 0 ? 0 : qrow[x];                   // (rows past the end cannot occur: blocks end at Tq)
+        const w_u32x4* qr = (const w_u32x4*)(qp + qc * a.q_st);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[x][ks] = qr[2 * ks + half];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[x][ks]));
-    dma_k(0); dma_v(0);
-    dma_k(1); dma_k(2);
-    dma_k(3); dma_v(1);                                    // = one trip's worth of pieces: may stay in flight
-    W_WAIT(1);
     W_BARRIER();
     {
-        const uint32_t kb = k_rd + 0 * W_KSTAGE;           // tile 0 -> K slot 0
-        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb, ks * 32); });
-        W_LGKM(0);
-        w_static_for<8>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, qf, S);
-            constexpr int ks = decltype(jc)::v;
-            if (ks == 0) { W_MFMA_S0(S[0][0], kf[ks], qf[0][ks]); W_MFMA_S0(S[1][0], kf[ks], qf[1][ks]); }
-            else { W_MFMA_S(S[0][0], kf[ks], qf[0][ks]); W_MFMA_S(S[1][0], kf[ks], qf[1][ks]); }
+        const uint32_t kb = k_rd + 0 * W_KSTAGE;           // tile 0 -> K slot 0: four batches of four fragments
+#define W_PRO_BATCH(F0)                                                                                                             \
+        w_static_for<4>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb); constexpr int f = (F0) + decltype(jc)::v;       \
+            W_DSR_K(kf[f & 3], kb, (f >> 3) * (32 * W_KROW) + (f & 7) * 32); });                                                      \
+        W_LGKM(0);                                                                                                                    \
+        w_static_for<4>([&](auto jc) __attribute__((always_inline)) {                                                                 \
+            W_USE3(kf, qf, S);                                                                                                        \
+            constexpr int f = (F0) + decltype(jc)::v, kt = f >> 3, ks = f & 7;                                                        \
+            if (ks == 0) { W_MFMA_S0(S[0][kt], kf[f & 3], qf[0][ks]); W_MFMA_S0(S[1][kt], kf[f & 3], qf[1][ks]); }                    \
+            else { W_MFMA_S(S[0][kt], kf[f & 3], qf[0][ks]); W_MFMA_S(S[1][kt], kf[f & 3], qf[1][ks]); }                              \
         });
-        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32); });
-        W_LGKM(0);
-        w_static_for<8>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, qf, S);
-            constexpr int ks = decltype(jc)::v;
-            if (ks == 0) { W_MFMA_S0(S[0][1], kf[ks], qf[0][ks]); W_MFMA_S0(S[1][1], kf[ks], qf[1][ks]); }
-            else { W_MFMA_S(S[0][1], kf[ks], qf[0][ks]); W_MFMA_S(S[1][1], kf[ks], qf[1][ks]); }
-        });
+        W_PRO_BATCH(0) W_PRO_BATCH(4) W_PRO_BATCH(8) W_PRO_BATCH(12)
         W_NOP24();                                         // MFMA results -> the VALU below
         if (0 >= mask_from) mask_tile(0);
         __builtin_amdgcn_sched_barrier(0);
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) { side(decltype(jc)::v); });
         resc = false;                                      // (O is still zero)
         const uint32_t kb1 = k_rd + 1 * W_KSTAGE;          // tile 1 -> K slot 1: its first-half fragments
-        w_static_for<8>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb1); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb1, ks * 32); });
+        w_static_for<4>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb1); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb1, ks * 32); });
         W_LGKM(0);
         W_BARRIER();                                       // every wave is done with K slot 0 before trip 0 refills it with tile 4
     }
@@ -503,6 +542,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                     oacc[x][dt] = oacc[x][dt] * alpha[x];
                     asm volatile("" : "+a"(oacc[x][dt]));
                 }
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                lacc[x] = lacc[x] * alpha[x];
+                asm volatile("" : "+a"(lacc[x]));
+            }
             W_NOP24();
         }
 
@@ -521,9 +565,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                 else W_M0P(vslot, pc);
             }
 #endif
-            if (kt == 1 && x == 0) W_T_LGKM(w_wait_k1(ks));
-            if (ks == 0) W_MFMA_S0(S[x][kt], kf[ks], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[ks], qf[x][ks]);
-            if (x == 1 && kt == 0) W_T_DSR_K(kf[ks], kb, 32 * W_KROW + ks * 32);
+            constexpr int f = i >> 1;                     // K fragment of this MFMA
+            if (f >= 4 && x == 0) W_T_LGKM(w_wait_k1(f));
+            if (ks == 0) W_MFMA_S0(S[x][kt], kf[f & 3], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[f & 3], qf[x][ks]);
+            if (x == 1 && f + 4 < 16) W_T_DSR_K(kf[f & 3], kb, ((f + 4) >> 3) * (32 * W_KROW) + ((f + 4) & 7) * 32);
             if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragments of P.V(tile)
                 constexpr int p = (i - (32 - 2 * W_VD)) >> 1;
 #ifdef W_ABL_VADDRK
@@ -532,10 +577,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                 W_T_DSR_V(vfr[p], vb[p >> 2], (p & 3) * 4096);
 #endif
             }
-            // five instructions of the exp stream per gap (160 = 32 x 5)
+            // three instructions of the exp stream per gap (96 = 32 x 3)
 #ifndef W_ABL_NOEXP
+#if W_LSUM_MFMA
+            exp_op((3 * i) / 6, (3 * i) % 6); exp_op((3 * i + 1) / 6, (3 * i + 1) % 6); exp_op((3 * i + 2) / 6, (3 * i + 2) % 6);
+#else
             exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
             exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
+#endif
 #endif
 #ifndef W_ABL_NODMA
             if (dma) {
@@ -546,8 +595,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
+#if !W_LSUM_MFMA
 #pragma unroll
         for (int x = 0; x < 2; ++x) l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
+#endif
         if (mask_nxt) {
             W_NOP24();
             mask_tile(tile + 1);
@@ -560,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         w_srd_t ksrd_n = ksrd, vsrd_n = vsrd;
         bool mask_nxt_n = false;
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, oacc, kb2); W_USE3(vb, vfr, pk); W_USE2(S, ev);
+            W_USE3(kf, oacc, kb2); W_USE3(vb, vfr, pk); W_USE2(S, ev); W_USE2(lacc, ones);
             constexpr int j = decltype(jc)::v;
             constexpr int p = j >> 1, x = j & 1;
             constexpr int g = p >> 2, dt = p & 3;
@@ -568,6 +619,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             w_u32x4 pf;
             pf.x = pk[x][4 * g]; pf.y = pk[x][4 * g + 1]; pf.z = pk[x][4 * g + 2]; pf.w = pk[x][4 * g + 3];
             W_MFMA_O(oacc[x][dt], vfr[p % (W_VD + 1)], pf);
+#if W_LSUM_MFMA && !defined(W_ABL_NOLSUM)
+            if (dt == 3) W_MFMA_L(lacc[x], ones, pf);     // the group's column sums (its P^T fragment is in registers now)
+#endif
             if (x == 0 && p + W_VD < 16) {
                 constexpr int pp = p + W_VD;
 #ifdef W_ABL_VADDRK
@@ -576,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
                 W_T_DSR_V(vfr[pp % (W_VD + 1)], vb[pp >> 2], (pp & 3) * 4096);
 #endif
             }
-            if (x == 0 && j >= 8 && j <= 22) W_T_DSR_K(kf[(j - 8) >> 1], kb2, ((j - 8) >> 1) * 32);
+            if (j >= 10 && j <= 22 && ((j - 10) & 3) == 0) W_T_DSR_K(kf[(j - 10) >> 2], kb2, ((j - 10) >> 2) * 32);
 #ifndef W_ABL_NOSIDE
             side(j);
 #endif
@@ -611,7 +665,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     // ---- epilogue: normalise; the two halves of a row trade 8-byte pieces so that every lane stores 16 contiguous bytes -------------------
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
+#if W_LSUM_MFMA
+        const float l_tot = lacc[x][0];                                         // (every row of l^T holds the column's sum over all keys)
+#else
         const float l_tot = w_xor32_add(l_run[x]);
+#endif
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         const bool ok = x == 0 ? row_ok0 : row_ok1;
         uint16_t* orow = a.o + ((int64_t)(bat * a.Tq + (x == 0 ? orow_first : orow_second)) * a.H + head) * DH;
