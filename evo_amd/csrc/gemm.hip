@@ -42,7 +42,6 @@ typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
 struct GemmArgs {
     const unsigned char* x; const unsigned char* w; const uint16_t* bias; const uint16_t* res; uint16_t* y;
     int64_t M; int N; int K;
-    int64_t Mtot;                                              // MODE 2: rows of a group's plane (>= M: the caller may compute a row range)
     int tiles_n; int n_tiles; int tiles_m; int group_m;
 };
 
@@ -352,7 +351,7 @@ static_assert(!GE_FULL || GE_ORDER == 1, "GE_FULL pairs the strips of GE_ORDER 1
 //   [row block of 128][K / 16 groups][128 rows][16 channels] bf16 -- a 64-channel slab of a row is four 32-byte pieces 4 KiB apart
 //   instead of one 128-byte piece; only the DMA's SOURCE addresses change (the lane that fills granule s of LDS row r fetches
 //   32-byte piece s >> 1, half s & 1), the k-step is 16 KiB instead of 128 B; the tile origin m0 * K * 2 is the same number.
-template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; 2: group-major z for the Hyena operator;
+template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; (2: retired with csrc/hyena_cs.hip in round 5);
                                                             // 3: y [M, N] with the bias indexed by ROW (the swapped-operand launch: evo_linear_t_mfma_bf16)
 __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     constexpr uint32_t XSTEP = XB ? 16384u : (uint32_t)(GBK * 2);   // bytes from one k-step's X slab to the next
@@ -697,49 +696,6 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) asm volatile("" :: "v"(ost[k]));
                 GR_STAMP(8);
-            } else if constexpr (MODE == 2) {
-                // ---- group-major output for the Hyena operator: z [N / 48 groups][Mtot rows][48 = x2 | x1 | v of 16 channels].  The columns
-                // come in grouped order (row-permuted weight), a lane's eight consecutive columns are one 16-byte chunk of ONE group's
-                // row (48 % 8 == 0): chunk cc = column / 8 -> group cc / 6, chunk cc % 6 of the 96-byte row.  One descriptor over the
-                // whole tensor; rows past M get an offset beyond it (a row past the end would otherwise land in the next group's plane).
-                const uint64_t y64 = (uint64_t)a.y;
-                const g_u32x4 yd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)(a.Mtot * a.N * 2), 0x00020000u};
-                g_u32x4 bq[4], ost[8];
-                if (BIAS) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[b]) : "v"(ep_boff), "s"(a.bias + n0 + b * 32) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
-                }
-                const uint32_t mtot = (uint32_t)a.Mtot;
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int b = GE_B(u), j = GE_J(u);
-                    __builtin_amdgcn_sched_barrier(0);
-                    float v[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(acc[2 * b][j][r]));
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[4 + r]) : "a"(acc[2 * b + 1][j][r]));
-                    }
-                    GR_ZERO1(2 * b, j); GR_ZERO1(2 * b + 1, j);
-                    if (BIAS) {
-                        v[0] += bf_lo(bq[b][0]); v[1] += bf_hi(bq[b][0]); v[2] += bf_lo(bq[b][1]); v[3] += bf_hi(bq[b][1]);
-                        v[4] += bf_lo(bq[b][2]); v[5] += bf_hi(bq[b][2]); v[6] += bf_lo(bq[b][3]); v[7] += bf_hi(bq[b][3]);
-                    }
-                    const uint32_t cc = (uint32_t)((n0 + wn * 128 + 32 * b) >> 3) + (uint32_t)lq;      // < 8,192: cc / 6 = cc * 10923 >> 16
-                    const uint32_t grp = (cc * 10923u) >> 16;
-                    const uint32_t m = (uint32_t)(m0 + wm * 128 + 16 * j + l15);
-                    const uint32_t off = (int64_t)m < a.M ? (grp * mtot + m) * 96u + (cc - 6u * grp) * 16u : 0xfffffff0u;
-                    g_u32x4& o = ost[u & 7];
-                    o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); o[2] = pack_bf2(v[4], v[5]); o[3] = pack_bf2(v[6], v[7]);
-                    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" GE_STPOL :: "v"(o), "v"(off), "s"(yd) : "memory");
-                    if (u >= 7) asm volatile("" :: "v"(ost[(u + 1) & 7]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) asm volatile("" :: "v"(ost[k]));
-                GR_STAMP(8);
             } else {
             const int rows_ok = a.M - m0 < GBM ? (int)(a.M - m0) : GBM;
             const uint64_t y64 = (uint64_t)(MODE == 3 ? a.y + ((int64_t)(n0 / GBN) * a.M + m0) * GBN : a.y + m0 * a.N);
@@ -867,14 +823,13 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
     GemmArgs a;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias;
     a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
-    a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = M;
+    a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)((M + GBM - 1) / GBM);
     // raster width: the ~32 tiles an XCD runs at once cover group_m X panels x 32 / group_m W panels.  Measured on the four layer
     // shapes at M = 65,536 (tools/gemm_ab.py lib.so@G): N = 12,288 / 22,016: 8 is best (98.1 / 98.2 % of hipBLASLt against 97.6 /
     // 96.6 at 4, 88 at 16, 60 at 32); N = 4,096 (16 column tiles): 1-4 tie, 8 loses 1.5-2.5 %.  EVO_GEMM_GROUP_M overrides.
-    static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-    const int group_m = group_env >= 1 ? group_env : (a.tiles_n >= 32 ? 8 : 4);
+    const int group_m = (a.tiles_n >= 32 ? 8 : 4);
     a.group_m = group_m;
     const int64_t tiles = ((M + GBM - 1) / GBM) * a.tiles_n;
     if (tiles > 0x7fffffff) return -1;
@@ -913,7 +868,7 @@ extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const
     GemmArgs a;
     a.x = (const unsigned char*)x_blk; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias;
     a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
-    a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = M;
+    a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)(M / GBM);
     a.group_m = a.tiles_n >= 32 ? 8 : 4;
@@ -943,11 +898,10 @@ extern "C" int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a_o
     if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w12g; a.bias = nullptr; a.res = nullptr; a.y = (uint16_t*)a_out;
-    a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = M;
+    a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)((M + GBM - 1) / GBM);
-    static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-    a.group_m = group_env >= 1 ? group_env : (a.tiles_n >= 32 ? 8 : 4);
+    a.group_m = (a.tiles_n >= 32 ? 8 : 4);
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
     if (tiles > 0x7fffffff) return -1;
     a.n_tiles = (int)tiles;
@@ -960,36 +914,6 @@ extern "C" int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a_o
     hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 1>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }
-
-// Hyena projection with a GROUP-MAJOR result: z [N / 48][Mtot][48] bf16 = (x [M, K] . w [N, K]^T + bias [N]) with the columns of w in
-// the grouped order of the single-pass Hyena operator ([16-channel group][x2 | x1 | v]: evo_amd/hyena_tables.py group_permutation), so that
-// every workgroup of evo_hyena_mfma_zg reads one contiguous stream.  Rows 0 .. M - 1 of every plane are written (M <= Mtot: the caller
-// may route a row sliver elsewhere).  N % 256 == 0, N % 48 == 0, K % 64 == 0, K >= 128, Mtot * N * 2 < 4 GiB.
-extern "C" int evo_linear_zg_mfma_bf16(const void* x, const void* w, const void* bias, void* z, int64_t M, int64_t Mtot, int64_t N,
-                                       int64_t K, void* stream) {
-    if (M <= 0 || Mtot < M || N <= 0 || K <= 0 || N % GBN != 0 || N % 48 != 0 || K % GBK != 0 || K < 2 * GBK || N >= 65536) return -1;
-    if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll || Mtot * N * 2 >= 0xfffffff0ll) return -1;
-    GemmArgs a;
-    a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias; a.res = nullptr; a.y = (uint16_t*)z;
-    a.M = M; a.N = (int)N; a.K = (int)K; a.Mtot = Mtot;
-    a.tiles_n = (int)(N / GBN);
-    a.tiles_m = (int)((M + GBM - 1) / GBM);
-    static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-    a.group_m = group_env >= 1 ? group_env : (a.tiles_n >= 32 ? 8 : 4);
-    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
-    if (tiles > 0x7fffffff) return -1;
-    a.n_tiles = (int)tiles;
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        n &= ~7;
-        return n < 8 ? 8 : n;
-    }();
-    if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 2>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 2>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
-    return evo_launch_status();
-}
-
 
 // z^T = (x [Mp, K] . w [N, K]^T + bias [N])^T, stored in blocks of 256 positions, zt [Mp / 256][N][256] (element (feature c, position p) at
 // ((p / 256) * N + c) * 256 + p % 256): the Hyena projection with a CHANNEL-MAJOR result for csrc/hyena_ct.hip --
@@ -1004,11 +928,10 @@ extern "C" int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* 
     if (Mp * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
     a.x = (const unsigned char*)w; a.w = (const unsigned char*)x; a.bias = (const uint16_t*)bias; a.res = nullptr; a.y = (uint16_t*)zt;
-    a.M = N; a.N = (int)Mp; a.K = (int)K; a.Mtot = N;
+    a.M = N; a.N = (int)Mp; a.K = (int)K;
     a.tiles_n = (int)(Mp / GBN);
     a.tiles_m = (int)(N / GBM);
-    static const int group_env = [] { const char* e = getenv("EVO_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-    a.group_m = group_env >= 1 ? group_env : (a.tiles_m >= 32 ? 8 : 4);      // (column tiles per raster group: see tile_origin, MODE 3)
+    a.group_m = (a.tiles_m >= 32 ? 8 : 4);      // (column tiles per raster group: see tile_origin, MODE 3)
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
     if (tiles > 0x7fffffff) return -1;
     a.n_tiles = (int)tiles;

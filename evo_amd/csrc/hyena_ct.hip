@@ -1,12 +1,15 @@
-// Hyena operator, single pass over CHANNEL-MAJOR z (z^T), channel-stationary waves, no input window in LDS (gfx950).  Round 4.
+// Hyena operator, single pass over CHANNEL-MAJOR z (z^T), channel-stationary waves, no input window in LDS (gfx950).  Round 4; since
+// round 5 the ONLY single-pass form (its predecessors -- token-major hyena_mfma.hip of rounds 2-3, group-major hyena_cs.hip of round 4
+// -- are retired; their measurement notes stay under profiles/r03_*, profiles/r04_hyena_cs_notes.txt).
 //
-// The arithmetic and the division of labour are those of csrc/hyena_cs.hip (a wave owns two channels for a 512-step tile; lane
-// (la = lane & 15, lq = lane >> 4) holds steps 8 lq .. 8 lq + 7 of block la = its column of the B operand of
-// v_mfma_f32_16x16x32_bf16; rows of T0 / G permuted at load time so that a lane's accumulators are its own eight steps).  What
-// changes is where z comes from.  hyena_cs.hip reads GROUP-MAJOR z ([16-channel group][row][x2 | x1 | v]): the window of a tile is
-// DMA'd into LDS, published by a barrier and read back as 30 ds_read_b64 per wave and tile -- a column read of 8 bytes out of
-// 16-byte DMA granules, 2-way bank-conflicted by construction, half of every read unused (profiles/r04_hyena_cs_notes.txt: window
-// reads 1.5-2.4 k and DMA waits 0.6-0.7 k of the 7.7 k clocks a tile takes; SQ_LDS_BANK_CONFLICT 60 % of the LDS-active cycles).
+// Division of labour: a workgroup owns 16 channels of one batch row and walks the sequence in tiles of 512 steps; a wave owns two
+// channels for the whole tile.  Lane (la = lane & 15, lq = lane >> 4) holds steps 8 lq .. 8 lq + 7 of 32-step block la: its FIR outputs
+// ARE its column of the B operand of v_mfma_f32_16x16x32_bf16 (block-Toeplitz product T0 and block aggregates G, operands split into
+// bf16 hi + lo terms, fp32 accumulation; the rows of T0 / G are permuted at load time so that a lane's accumulators are its own eight
+// steps and meet the FIR'd x2 of the same lane), the 16 blocks' modal states meet in a DPP scan in fp32, the carry product runs on
+// the matrix cores again with hi/lo-split states.  No bf16 planes, no parked x2, no fp32 y^T travel through LDS.
+// Where z comes from is what makes this form: the group-major predecessor DMA'd a tile's window into LDS and read it back as 30
+// conflicted ds_read_b64 per wave and tile (window reads 1.5-2.4 k and DMA waits 0.6-0.7 k of the 7.7 k clocks a tile took).
 // Here z arrives TRANSPOSED, z^T [3 D columns][time] (stored in blocks of 256 positions): the projection's dense layer is launched
 // with its operands swapped (evo_linear_t_mfma_bf16, csrc/gemm.hip: out[n][m] = W . x^T, the same kernel, whole-line stores, an
 // output tile = one contiguous 128 KiB block), so a lane's eight steps of one
@@ -28,7 +31,7 @@
 #include "../../include/evo_mi355x.h"
 
 #ifndef HT_XLO
-#define HT_XLO 1                            // 1: X = x1 * v as bf16 hi + lo (hyena_cs.hip: the closed X_lo question)
+#define HT_XLO 1                            // 1: X = x1 * v as bf16 hi + lo (profiles/r04_hyena_cs_notes.txt: the closed X_lo question)
 #endif
 #define HT_NW 8                             // waves per workgroup, two per SIMD
 #define HT_CH 16
@@ -60,7 +63,7 @@ template <int D_>
 __device__ __forceinline__ float ht_shr(float v) {          // value of lane (a - D_) of the 16-lane row, 0 where a < D_
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + D_, 0xf, 0xf, true));
 }
-// two waves per SIMD share the matrix pipe: hipcc under-pads MFMA -> consumer distances (hyena_mfma.hip, round 2); bursts are fenced
+// two waves per SIMD share the matrix pipe: hipcc under-pads MFMA -> consumer distances (found on the round-2 kernel); bursts are fenced
 #define HT_FENCE_NOP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 struct ht_false { static constexpr bool value = false; };
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
         const int row = HT_RW * wave + 32 * hs + (lane >> 1);
         // bounds-checked buffer store: rows past the end (and the stores of the first interval, which has no previous tile) get an
         // offset beyond num_records and are dropped, so that the VM counter sees exactly HT_NST stores per interval.
-        // BLOCKED y (hyena_cs.hip, round 4): a group's 16 channels of 128 consecutive rows are 4 KiB: a store covers 8 whole lines.
+        // BLOCKED y (round 4): a group's 16 channels of 128 consecutive rows are 4 KiB: a store covers 8 whole lines.
         const uint32_t R = (uint32_t)(a.y_row0 + (int64_t)c.b * Ti + t0 + row);  // row of the [rows, D] matrix
         const uint32_t yb = ((R / HT_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HT_YBLK * 32) + (R % HT_YBLK) * 32 + (lane & 1) * 16;
         const uint32_t off = !(v.st && (full || t0 + row < Ti)) ? 0xfffffff0u : (a.y_blk ? yb : row0 + (uint32_t)row * yrb + (lane & 1) * 16);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
             // still needed for re'), so the im registers alternate from level to level.  Wait states: a VGPR written by a VALU
             // instruction may be read through DPP two instructions later at the earliest -- inside a level and from level to level
             // the order below keeps that distance (hand-written: the compiler does not look into inline asm); the leading / trailing
-            // s_nop cover the compiler's own instructions around the block.  (Identical to hyena_cs.hip.)
+            // s_nop cover the compiler's own instructions around the block.  
 #define HT_LEVEL(KK, SH, PRE, POST)                                                                                       \
             {                                                                                                             \
                 const ht_f32x4 Pw = pw4[(KK)];                                                                            \

@@ -12,7 +12,7 @@ T0 and W multiply bf16 data on the bf16 matrix cores, so they are stored as sums
 lo -- 2^-17 and 2^-25 relative).  G multiplies the fp32 block states: both are split hi + lo in bf16 (the kernel splits the
 states on the fly), G_hi S_hi + G_hi S_lo + G_lo S_hi on the bf16 matrix cores (2^-17; the fp32 matrix cores would be exact
 but 8x slower per product).  P stays fp32 (VALU).  Everything is evaluated in fp64 here,
-once per model load, and laid out in the MFMA operand order the kernel reads (csrc/hyena_mfma.hip).  The same numbers
+once per model load, and laid out in the MFMA operand order the kernel reads (csrc/hyena_ct.hip).  The same numbers
 drive the CPU emulation in tests/test_hyena_blocked.py.
 """
 from __future__ import annotations
@@ -67,7 +67,7 @@ def blocked_constants(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.
 
 
 # ---- MFMA operand order -------------------------------------------------------------------------------------------------
-# One table row per channel: 52 dwords per lane x 64 lanes, in the order csrc/hyena_mfma.hip keeps them in registers.
+# One table row per channel: 52 dwords per lane x 64 lanes, in the order csrc/hyena_ct.hip keeps them in registers.
 #   v_mfma_f32_16x16x32_bf16  A operand: lane l holds A[row = l & 15][k = 8 (l >> 4) + 0..7]  (4 dwords = 8 bf16)
 #   (B operands come from the data; C/D: lane l holds D[row = 4 (l >> 4) + r][col = l & 15], r = 0..3)
 TAB_T0 = 0          # [mt 2][split 2][4 dwords]   T0[16 mt + row][k]
@@ -120,7 +120,7 @@ def mfma_operand_table(poles: torch.Tensor, residues: torch.Tensor, dskip: torch
 
 
 # ---- grouped z layout ------------------------------------------------------------------------------------------------------
-GROUP = 16      # channels per workgroup of csrc/hyena_mfma.hip
+GROUP = 16      # channels per workgroup of csrc/hyena_ct.hip
 
 
 def group_permutation(D: int, n_heads: int, device=None) -> torch.Tensor:

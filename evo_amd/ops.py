@@ -1,9 +1,10 @@
 """ctypes binding of libevo_mi355x.so (include/evo_mi355x.h) and the op set the StripedHyena host code calls.
 
 `HipOps` is the ONLY compute backend the product ships: it raises if the shared library cannot be
-loaded or a tensor is not on a ROCm device -- there is no CPU / eager fallback.  Dense layers go to
-hipBLASLt through `torch.addmm` (SURVEY.md section 7 decision D1); everything else is a hand-written gfx950
-kernel reached through the C ABI with raw device pointers and the caller's current stream.
+loaded or a tensor is not on a ROCm device -- there is no CPU / eager fallback.  Every kernel of a scoring or generation
+step -- the dense layers included (csrc/gemm.hip, csrc/gemv.hip) -- is a hand-written gfx950 kernel reached through the C ABI with
+raw device pointers and the caller's current stream; hipBLASLt (through `torch.addmm`) serves only shapes no 7B layer has and the
+in-process A/B knob `all_gemm_mfma = False`.
 """
 from __future__ import annotations
 
@@ -37,9 +38,6 @@ _SIGNATURES = {
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_mfma_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_linear_zg_mfma_bf16": ([_PTR] * 4 + [_I64] * 4 + [_PTR], _c.c_int),
-    "evo_hyena_mfma_zg": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
-    "evo_hyena_cs_zg": ([_PTR] * 9 + [_I64] * 8 + [_PTR], _c.c_int),
     "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 12 + [_PTR], _c.c_int),
     "evo_linear_t_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
@@ -51,8 +49,6 @@ _SIGNATURES = {
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_unembed_logprob_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_hyena_mfma": ([_PTR] * 10 + [_I64] * 4 + [_PTR], _c.c_int),
-    "evo_hyena_mfma_state": ([_PTR] * 8 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_rope_append_decode_bf16": ([_PTR] * 4 + [_F32] + [_I64] * 7 + [_PTR], _c.c_int),
 }
 
@@ -178,16 +174,11 @@ class HipOps:
         self.all_gemm_mfma = True
         # the gated MLP's first half as ONE launch of the dense layer with GELU * gate in its epilogue; False: dense layer + gate kernel
         self.mlp_gate_fused = True
-        # the Hyena operator's input GROUP-MAJOR ([D / 16][B T][48], written that way by the projection's dense layer: every workgroup
-        # of the operator reads one contiguous stream); False: token-major [B, T, 3 D] and the round-3 kernel
-        self.hyena_zg = True
         self.timer: Optional[KernelTimer] = None
         self.validate_ids = os.environ.get("EVO_AMD_VALIDATE_IDS", "1") != "0"   # one 4-byte D2H read per forward
-        self.hyena_mfma = True          # the single-pass matrix-core operator (False: the modal three-launch kernels; tests' yardstick)
-        # ... on group-major z by the channel-stationary kernel (csrc/hyena_cs.hip, round 4) with a blocked y; False: the round-3 kernel
-        self.hyena_cs_flag = True
-        # ... or on CHANNEL-MAJOR z^T (csrc/hyena_ct.hip: the projection launched with swapped operands, no input window in LDS);
-        # False: group-major z and hyena_cs.hip
+        # the single-pass matrix-core Hyena operator on CHANNEL-MAJOR z^T (csrc/hyena_ct.hip: the projection launched with swapped
+        # operands, no input window in LDS); False: the modal three-launch kernels (the tests' yardstick, padding masks, tiny inputs)
+        self.hyena_mfma = True
         self.hyena_ct_flag = True
         self._xpad = threading.local()  # per thread: the zero-initialised padded input of the swapped-operand projection (_xpad_buffer)
         self.last_hyena_io = {}
@@ -386,28 +377,36 @@ class HipOps:
         return (self.hyena_ct_flag and B * T >= 256 and N % 256 == 0 and N % 384 == 0 and K % 64 == 0 and K >= 128
                 and Mp * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and P * N * 2 < 0xfffffff0)
 
-    def _xpad_buffer(self, rows: int, D: int, device) -> torch.Tensor:
-        """The cached [rows, D] bf16 workspace of rmsnorm_rows: zero-initialised once, ONE shape at a time (a scoring run keeps its
-        shape; a new shape replaces the buffer) and one instance PER THREAD (callers that drive one HipOps from several threads --
-        the virtual ranks of the sequence-parallel tests, a server's worker threads -- must not share it: launches of different
-        threads are not ordered with each other)."""
-        key = (rows, D, str(device))
+    def _xpad_buffer(self, B: int, T: int, D: int, device) -> torch.Tensor:
+        """The cached [Mp + 16, D] bf16 workspace of rmsnorm_rows: ONE layout at a time (a scoring run keeps its shape; another (B, T)
+        -- even one with the same number of rows -- replaces the buffer by a freshly zeroed one, so pad rows never hold another
+        layout's activations), one instance PER THREAD (callers that drive one HipOps from several threads -- the virtual ranks of the
+        sequence-parallel tests, a server's worker threads -- must not share it: launches of different threads are not ordered with each
+        other) and per STREAM (a second stream would otherwise reuse it with no event ordering).  Pad rows are zero when the buffer is
+        made and never written by rmsnorm_rows; what the projection computes from them lands in pad positions of z^T, which hyena_ct
+        masks.  `release_workspaces()` drops it (a long-lived server between shapes)."""
+        key = (B, T, D, str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
         cur = getattr(self._xpad, "entry", None)
         if cur is None or cur[0] != key:
-            cur = (key, torch.zeros(rows, D, dtype=torch.bfloat16, device=device))
+            _, _, Mp, _ = self.zt_layout(B, T)
+            cur = (key, torch.zeros(Mp + 16, D, dtype=torch.bfloat16, device=device))
             self._xpad.entry = cur
         return cur[1]
+
+    def release_workspaces(self) -> None:
+        """Frees this thread's cached rmsnorm_rows workspace (0.5 GB at 8 x 8,193, 1 GB at 1 x 131,073 for D = 4096)."""
+        self._xpad.entry = None
 
     def rmsnorm_rows(self, x: torch.Tensor, scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
         """RMSNorm of x [B T, D] written in the row order of zt_layout: -> [Mp + 16, D], row b T + t at its z^T position for t < Tm, the
         B r tail tokens compactly at rows Mp + b r + (t - Tm) (the weight-streaming kernel's input).  The buffer is a cached workspace
-        (_xpad_buffer: the pad rows are zero and never written), valid until this thread's next call."""
+        (_xpad_buffer: pad rows are zero and never written), valid until this thread's next call on this stream."""
         self._need(x, torch.bfloat16, "rmsnorm x")
         self._need(scale, torch.bfloat16, "rmsnorm scale")
         M, D = x.shape
         assert M == B * T
         Tm, Tp, Mp, r = self.zt_layout(B, T)
-        out = self._xpad_buffer(Mp + 16, D, x.device)
+        out = self._xpad_buffer(B, T, D, x.device)
         with self._t("rmsnorm"):
             _check(self.lib.evo_rmsnorm_rows_bf16(x.data_ptr(), None, scale.data_ptr(), out.data_ptr(), M, D, float(eps), T, Tp, Tm, Mp,
                                                   _stream()), "evo_rmsnorm_rows_bf16")
@@ -428,6 +427,7 @@ class HipOps:
             _check(self.lib.evo_linear_t_mfma_bf16(xp.data_ptr(), w.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K, _stream()),
                    "evo_linear_t_mfma_bf16")
         if r:
+            zt[-1].zero_()                                                                # (6 MB: the tail block's unused positions hold zeros, not whatever the allocator left)
             z_tail = self._linear_small_m(xp[Mp:Mp + B * r], w, b, None)                # [B r, N]
             zt[-1].view(N, 32, 8)[:, :B, :r] = z_tail.view(B, r, N).permute(2, 0, 1)      # position Mp + 8 b + j
         return zt
@@ -457,8 +457,10 @@ class HipOps:
                  state_only=False, b_first=0, y_blk=None, y_row0=0, b_total=None):
         """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [blocks, 3 D, 256] bf16 =
         linear_t's result (zt_layout of a [b_total, T] batch; b_total defaults to b_first + B); B batch rows of T tokens starting at
-        batch row `b_first` of the tensor (a sub-range).  Arguments and results as hyena_cs; `z_halo` [B, 2, 3 D] in the REFERENCE's
-        column order."""
+        batch row `b_first` of the tensor (a sub-range).  -> y [B,T,D] bf16 | (y, end state [B,D,8] complex64) with `want_state` | the end state alone with `state_only` (stage 1 of a
+        sequence-parallel shard: nothing else is written).  `z_halo` [B, 2, 3 D] in the REFERENCE's column order, `s0` [B,D,8] complex:
+        FIR history / modal state before the first token.  `y_blk` (from yblk_empty): the outputs go THERE, blocked, batch row b /
+        token t as row y_row0 + b T + t -- the form the kernel stores fastest and linear_residual_yblk_ reads."""
         self._need(zt, torch.bfloat16, "hyena z^T")
         assert zt.dim() == 3 and zt.shape[2] == 256
         D3, P = zt.shape[1], zt.shape[0] * 256
@@ -508,23 +510,11 @@ class HipOps:
                       residues: torch.Tensor, dskip: torch.Tensor, n_heads: int,
                       z_halo: Optional[torch.Tensor] = None, s0: Optional[torch.Tensor] = None,
                       want_state: bool = False, seg_len: Optional[int] = None,
-                      mask: Optional[torch.Tensor] = None, table: Optional[torch.Tensor] = None
-                      ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                      mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """z [B,T,3D] bf16 -> y [B,T,D] bf16 (+ complex64 state [B,D,8] after the last token).  `mask` [B,T] (bool /
-        uint8, 1 = token) is upstream's padding_mask: padded positions get a zero FIR output.  `table` (the layer's
-        hyena_tables.mfma_operand_table) enables the single-pass matrix-core kernel for plain scoring shapes (no
-        mask; carry-in state and end state included since round 3); masks and explicit segment lengths take the three-launch
-        modal form."""
-        if (table is not None and self.hyena_mfma and mask is None and seg_len is None
-                and z.shape[2] == 3 * n_heads * 128):
-            # (test / tool convenience: the product hands the matrix-core kernel a z the projection GEMM already wrote
-            #  in the grouped layout -- see StripedHyena._hyena_block)
-            from .hyena_tables import group_permutation
-            perm = group_permutation(z.shape[2] // 3, n_heads, z.device)
-            halo_g = None if z_halo is None else z_halo[..., perm].contiguous()
-            out = self.hyena_mfma_prefill(z[..., perm].contiguous(), fir_w, fir_b, dskip, table, n_heads, halo_g,
-                                          s0=s0, want_state=want_state, poles=poles)
-            return out if want_state else (out, None)
+        uint8, 1 = token) is upstream's padding_mask: padded positions get a zero FIR output.  The three-launch MODAL form
+        (csrc/hyena.hip: segment states, carry scan, apply) on token-major z: padding masks, inputs the single-pass kernel's
+        contract excludes, and the yardstick the tests hold hyena_ct against."""
         if mask is not None:
             mask = mask.to(device=z.device, dtype=torch.uint8).contiguous()
             assert mask.shape == z.shape[:2]
@@ -565,100 +555,10 @@ class HipOps:
                               "apply": z.numel() * 2 + y.numel() * 2 + agg.numel() * 4}
         return y, state
 
-    def linear_zg_shape_ok(self, M: int, N: int, K: int) -> bool:
-        """Shape part of linear_zg_ok (a pure function of the sizes: sequence-parallel ranks evaluate it on the SAME numbers)."""
-        return (self.hyena_zg and M >= 256 and N % 256 == 0 and N % 48 == 0 and N < 65536 and K % 64 == 0 and K >= 128
-                and M * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and M * N * 2 < 0xfffffff0)
-
-    def linear_zg_ok(self, x: torch.Tensor, w: torch.Tensor) -> bool:
-        """The projection of a Hyena block as a dense layer with a GROUP-MAJOR result (csrc/gemm.hip, mode 2)."""
-        M, K = x.shape
-        N = w.shape[0]
-        return (self.linear_zg_shape_ok(M, N, K)
-                and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous())
-
-    @staticmethod
-    def zg_rows(zg: torch.Tensor, B: int, T: int, t0: int, n: int) -> torch.Tensor:
-        """Rows t0 .. t0 + n - 1 of every batch row of a group-major z [G, B T, 48] as token-major [B, n, 3 D] (grouped column order)."""
-        G = zg.shape[0]
-        return zg.view(G, B, T, 48)[:, :, t0:t0 + n, :].permute(1, 2, 0, 3).reshape(B, n, G * 48)
-
-    @staticmethod
-    def zg_set_rows(zg: torch.Tensor, B: int, T: int, t0: int, rows: torch.Tensor) -> None:
-        """The inverse: write token-major rows [B, n, 3 D] (grouped column order) into rows t0 .. of every batch row of zg."""
-        G = zg.shape[0]
-        n = rows.shape[1]
-        zg.view(G, B, T, 48)[:, :, t0:t0 + n, :] = rows.view(B, n, G, 48).permute(2, 0, 1, 3)
-
-    def linear_zg(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """z [N / 48, M, 48] bf16 = x [M, K] @ w[N, K]^T (+ b), the columns of w in the grouped order of the single-pass Hyena
-        operator: the layout evo_hyena_mfma_zg reads (one contiguous stream per 16-channel group).  The BOS sliver (M % 256 <= 16
-        rows) goes through the weight-streaming kernel and is copied into the planes."""
-        M, K = x.shape
-        N = w.shape[0]
-        z = torch.empty(N // 48, M, 48, dtype=torch.bfloat16, device=x.device)
-        r = self._tail_rows(x, w)
-        with self._t("gemm_zg"):
-            _check(self.lib.evo_linear_zg_mfma_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), z.data_ptr(), M - r, M, N, K, _stream()),
-                   "evo_linear_zg_mfma_bf16")
-        if r:
-            z[:, M - r:, :] = self._linear_small_m(x[M - r:], w, b, None).view(r, N // 48, 48).transpose(0, 1)
-        return z
-
-    def hyena_mfma_prefill(self, z, fir_w, fir_b, dskip, table, n_heads, z_halo=None, s0=None, want_state=False,
-                           poles=None, zg_shape=None):
-        """Single-pass matrix-core Hyena operator (csrc/hyena_mfma.hip): z [B,T,3D] bf16 in the GROUPED column layout
-        (hyena_tables.group_permutation; fir_w / fir_b / dskip / poles / states stay in the reference's channel order)
-        -> y [B,T,D] bf16, or (y, state [B,D,8] complex64 after the last token) with `want_state` (needs `poles`).
-        `z_halo` [B,2,3D] (grouped) and `s0` [B,D,8] complex continue a sequence (cached prefill, sequence-parallel shard).
-        `zg_shape` = (B, T): z is the GROUP-MAJOR tensor [D / 16, B * T, 48] of linear_zg (same values, same results)."""
-        self._need(z, torch.bfloat16, "hyena z")
-        if zg_shape is not None:
-            B, T = zg_shape
-            D3 = z.shape[0] * 48
-            assert tuple(z.shape) == (D3 // 48, B * T, 48)
-        else:
-            B, T, D3 = z.shape
-        D = D3 // 3
-        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b"), (dskip, "dskip")):
-            self._need(t, torch.bfloat16, "hyena " + nm)
-        if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
-            raise RuntimeError("hyena_mfma: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
-        if z_halo is not None:
-            self._need(z_halo, torch.bfloat16, "hyena z_halo")
-            assert z_halo.shape == (B, 2, D3)
-        s0r = None
-        if s0 is not None:
-            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
-            assert s0r.shape == (B, D, 8, 2) and s0r.is_cuda
-        s_fin = None
-        if want_state:
-            if poles is None:
-                raise RuntimeError("hyena_mfma: the end state needs the poles")
-            self._need(poles, torch.float32, "hyena poles")
-            assert tuple(poles.shape) == (D, 8, 2)
-            s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
-        y = torch.empty(B, T, D, dtype=torch.bfloat16, device=z.device)
-        if zg_shape is not None and self.hyena_cs_flag:
-            with self._t("hyena_mfma"):
-                _check(self.lib.evo_hyena_cs_zg(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(),
-                                                y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, B * T, 0, 0, 0,
-                                                _stream()), "evo_hyena_cs_zg")
-        else:
-            fn = self.lib.evo_hyena_mfma if zg_shape is None else self.lib.evo_hyena_mfma_zg
-            with self._t("hyena_mfma"):
-                _check(fn(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), dskip.data_ptr(),
-                          table.data_ptr(), y.data_ptr(), _ptr(s0r), _ptr(s_fin), _ptr(poles),
-                          B, T, D, n_heads, _stream()), "evo_hyena_mfma" if zg_shape is None else "evo_hyena_mfma_zg")
-        self.last_hyena_io = {"mfma": z.numel() * 2 + y.numel() * 2}
-        if want_state:
-            return y, torch.view_as_complex(s_fin)
-        return y
-
-    YBLK = 128          # rows per block of the blocked y layout (csrc/hyena_cs.hip HC_YBLK)
+    YBLK = 128          # rows per block of the blocked y layout (csrc/hyena_ct.hip)
 
     def yblk_empty(self, rows: int, D: int, device) -> torch.Tensor:
-        """Uninitialised BLOCKED y for a [rows, D] matrix: [ceil(rows / 128), D / 16, 128, 16] bf16 (hyena_cs writes it, the output
+        """Uninitialised BLOCKED y for a [rows, D] matrix: [ceil(rows / 128), D / 16, 128, 16] bf16 (hyena_ct writes it, the output
         projection's dense layer reads it: linear_residual_yblk_)."""
         return torch.empty((rows + self.YBLK - 1) // self.YBLK, D // 16, self.YBLK, 16, dtype=torch.bfloat16, device=device)
 
@@ -668,60 +568,8 @@ class HipOps:
         nrb, G, R, c = y_blk.shape
         return y_blk.permute(0, 2, 1, 3).reshape(nrb * R, G * c)[:rows]
 
-    def hyena_cs(self, zg, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
-                 state_only=False, row0=0, y_blk=None, y_row0=0):
-        """The channel-stationary single-pass operator (csrc/hyena_cs.hip: evo_hyena_cs_zg) on B batch rows of T tokens of a
-        GROUP-MAJOR z [D / 16, rows_total, 48] bf16 (linear_zg's result), the first at row `row0` of every group's plane
-        (`row0` = b0 * T selects a sub-range of batch rows of a larger tensor: the row groups of a sequence-parallel shard).
-        -> y [B,T,D] bf16 | (y, end state [B,D,8] complex64) with `want_state` | the end state alone with `state_only`
-        (stage 1 of a sequence-parallel shard: nothing else is written).  `z_halo` [B,2,3D] (grouped column order), `s0`
-        [B,D,8] complex: FIR history / modal state before the first token.
-        `y_blk` (from yblk_empty): the outputs go THERE, blocked, batch row b / token t as row y_row0 + b T + t -- the form the
-        kernel stores fastest and linear_residual_yblk_ reads; the return value is then y_blk (or (y_blk, state))."""
-        self._need(zg, torch.bfloat16, "hyena z (group-major)")
-        G, rows_total, w48 = zg.shape
-        D = G * 16
-        assert w48 == 48 and 0 <= row0 and row0 + B * T <= rows_total
-        if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
-            raise RuntimeError("hyena_cs: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
-        for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b")):
-            self._need(t, torch.bfloat16, "hyena " + nm)
-        if z_halo is not None:
-            self._need(z_halo, torch.bfloat16, "hyena z_halo")
-            assert z_halo.shape == (B, 2, 3 * D)
-        s0r = None
-        if s0 is not None:
-            s0r = torch.view_as_real(s0.to(torch.complex64).contiguous())
-            assert s0r.shape == (B, D, 8, 2) and s0r.is_cuda
-        s_fin = None
-        if want_state or state_only:
-            if poles is None:
-                raise RuntimeError("hyena_cs: the end state needs the poles")
-            self._need(poles, torch.float32, "hyena poles")
-            assert tuple(poles.shape) == (D, 8, 2)
-            s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=zg.device)
-        yb_rows = 0
-        if state_only:
-            y = None
-        elif y_blk is not None:
-            self._need(y_blk, torch.bfloat16, "hyena y (blocked)")
-            assert y_blk.dim() == 4 and tuple(y_blk.shape[1:]) == (G, self.YBLK, 16)
-            yb_rows = y_blk.shape[0] * self.YBLK
-            assert 0 <= y_row0 and y_row0 + B * T <= yb_rows
-            y = y_blk
-        else:
-            y = torch.empty(B, T, D, dtype=torch.bfloat16, device=zg.device)
-        with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
-            _check(self.lib.evo_hyena_cs_zg(zg.data_ptr() + row0 * 96, _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(),
-                                            table.data_ptr(), _ptr(y), _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads,
-                                            rows_total, 1 if state_only else 0, yb_rows, y_row0, _stream()), "evo_hyena_cs_zg")
-        if state_only:
-            return torch.view_as_complex(s_fin)
-        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}
-        return (y, torch.view_as_complex(s_fin)) if want_state else y
-
     def linear_residual_yblk_(self, res: torch.Tensor, y_blk: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """res [M, N] += y @ w^T (+ bias, in the same epilogue: one rounding) with y given BLOCKED (hyena_cs's y_blk: [ceil(M / 128), K / 16, 128, 16]) -- the Hyena block's output
+        """res [M, N] += y @ w^T (+ bias, in the same epilogue: one rounding) with y given BLOCKED (hyena_ct's y_blk: [ceil(M / 128), K / 16, 128, 16]) -- the Hyena block's output
         projection on the hand-written dense layer (csrc/gemm.hip, X operand gathered from the blocked form); the last M % 256
         rows (the BOS sliver) go row-major through the weight-streaming kernel, as everywhere."""
         M, N = res.shape
@@ -741,25 +589,6 @@ class HipOps:
             tail = y_blk[nb0:].permute(0, 2, 1, 3).reshape(-1, K)[:r].contiguous()
             self.linear_residual_(res[Mf:], tail, w, bias=bias)
         return res
-
-    def hyena_mfma_state(self, z, fir_w, fir_b, table, n_heads, poles, z_halo=None, s0=None) -> torch.Tensor:
-        """End state [B,D,8] complex64 of the modal recurrence over z [B,T,3D] (GROUPED layout) -- the walk of
-        hyena_mfma_prefill without any output (csrc/hyena_mfma.hip, state-only build): stage 1 of a sequence-parallel shard."""
-        self._need(z, torch.bfloat16, "hyena z")
-        B, T, D3 = z.shape
-        D = D3 // 3
-        self._need(poles, torch.float32, "hyena poles")
-        assert tuple(poles.shape) == (D, 8, 2) and tuple(table.shape) == (D, 52, 64) and table.dtype == torch.int32
-        if z_halo is not None:
-            self._need(z_halo, torch.bfloat16, "hyena z_halo")
-            assert z_halo.shape == (B, 2, D3)
-        s0r = None if s0 is None else torch.view_as_real(s0.to(torch.complex64).contiguous())
-        s_fin = torch.empty(B, D, 8, 2, dtype=torch.float32, device=z.device)
-        with self._t("hyena_mfma_state"):
-            _check(self.lib.evo_hyena_mfma_state(z.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(),
-                                                 _ptr(s0r), s_fin.data_ptr(), poles.data_ptr(), B, T, D, n_heads, _stream()),
-                   "evo_hyena_mfma_state")
-        return torch.view_as_complex(s_fin)
 
     # The same operator in two stages, for sequence parallelism: stage 1 (launches 1+2) yields the shard's end
     # state from a ZERO carry-in; after the ranks exchange those, stage 2 (carry-add + launch 3) finishes.

@@ -7,7 +7,7 @@ evo/generation.py:105-155]:
     logits, cache = model(input_ids, inference_params_dict=None, padding_mask=None)
     cache = model.initialize_inference_params()
 with the state-dict key set of SURVEY.md section B.  All arithmetic is dispatched to an `ops` object:
-`evo_amd.ops.HipOps` (hand-written gfx950 kernels over the C ABI + hipBLASLt GEMMs) in the product.
+`evo_amd.ops.HipOps` (hand-written gfx950 kernels over the C ABI, the dense layers included) in the product.
 There is no CPU fallback here: with no `ops` injected and no usable HIP library the first forward raises.
 (`tests/` inject an oracle-backed ops object to exercise this host logic on CPU.)
 """
@@ -211,13 +211,26 @@ class StripedHyena(nn.Module):
                 f._poles = f.poles.data.reshape(D, self.state_size, 2).float().contiguous()
                 f._residues = f.residues.data.reshape(D, self.state_size, 2).float().contiguous()
                 # the [D,52,64] operand table of the matrix-core operator (54 MB per layer, 1.6 GB for the 29 Hyena layers of the 7B
-                # model): built by _mfma_table on the first parallel Hyena call of the layer (every bench / test does untimed warm-up
-                # passes first), never for decode-only use.  The row-permuted copy of the projection weight (100 MB per layer) is
-                # built only where the GROUP-MAJOR path runs (_mfma_pack: sequence-parallel shards, shapes outside the z^T contract);
-                # the channel-major path of round 4 reads the projection weight as it is.
-                f._mfma = None
+                # model): built by _mfma_table on the first parallel Hyena call of the layer -- or up front by prepare() --, never for
+                # decode-only use.  The operator reads the projection weight as it is (no regrouped copy).
                 f._mfma_tab = None
         self._packed = True
+
+    def prepare(self, prefill: bool = True) -> "StripedHyena":
+        """Builds the derived device-side tensors NOW instead of inside the first forward: the fused / padded MLP weights (always), and
+        with `prefill` the regrouped l1 | l2 copies of the one-launch gated MLP (5.8 GB at 7B) and the Hyena layers' MFMA operand tables
+        (1.6 GB) that prefill-sized batches use.  A server calls it at load time: an out-of-memory condition then surfaces before any
+        KV cache or activation exists, the first request does not pay the packing, and the tensors are ordinary (not inference-mode)
+        tensors whatever mode the first forward runs under.  Decode-only deployments pass prefill=False."""
+        with torch.inference_mode(False), torch.no_grad():
+            if not self._packed:
+                self._pack()
+            if prefill:
+                for blk in self.blocks:
+                    self._gate_pack(blk, 1 << 20)
+                    if isinstance(blk, _HyenaBlock) and hasattr(self.ops, "hyena_ct"):
+                        self._mfma_table(blk)
+        return self
 
     # ------------------------------------------------------------------ caches
     def initialize_inference_params(self):
@@ -288,7 +301,7 @@ class StripedHyena(nn.Module):
         RMSNorm pass for prefill-sized batches, into this launch for decode-sized ones)."""
         # round 4: the bias rides in the dense layer's epilogue at every batch size (x <- bf16(x + y W^T + b): one rounding where the
         # reference rounds twice); the post-mixer RMSNorm then reads x only (rmsnorm_kernel<false>: 4 D instead of 6 D bytes per token)
-        if y.dim() == 4:                                     # the Hyena operator's blocked output (ops.hyena_cs)
+        if y.dim() == 4:                                     # the Hyena operator's blocked output (ops.hyena_ct)
             self.ops.linear_residual_yblk_(x2d, y, w, bias=bias)
             return None
         self.ops.linear_residual_(x2d, y, w, mfma=mfma, bias=bias)
@@ -322,16 +335,14 @@ class StripedHyena(nn.Module):
         ops.linear_residual_(x2d, a, blk.mlp._w3)
 
     def _mfma_hyena_ok(self, B: int, T: int) -> bool:
-        """The single-pass matrix-core operator serves every parallel (T > 1) Hyena call without a padding mask on the HIP
-        backend -- scoring, and cached prefill with carry-in / end state -- when the shape fits its launch contract
-        (include/evo_mi355x.h: evo_hyena_mfma); masks and very short inputs take the modal kernels."""
+        """The single-pass matrix-core operator (csrc/hyena_ct.hip) serves every parallel (T > 1) Hyena call without a padding mask on
+        the HIP backend -- scoring, cached prefill with carry-in / end state, sequence-parallel shards -- when the shape fits its launch
+        contract; masks and very short inputs take the modal kernels.  (Shape part only: _hyena_ct_ok adds the tensors' checks.)"""
         ops = self.ops
         D, H = self.hidden_size, self.num_heads
-        if not getattr(ops, "hyena_mfma", False) or not hasattr(ops, "hyena_mfma_prefill") or D != H * 128:
+        if not getattr(ops, "hyena_mfma", False) or not hasattr(ops, "hyena_ct") or D != H * 128:
             return False
-        groups = D // 16
-        split = min(B, (256 + groups - 1) // groups)
-        return T >= 32 and B * T >= 256 and B * T * D * 2 < 0xfffffff0 and (groups * split) % 8 == 0
+        return T >= 32 and B * T >= 256
 
     def _mfma_table(self, blk):
         """The MFMA operand table of a Hyena block's filter (evo_amd/hyena_tables.py), built on first use."""
@@ -340,19 +351,6 @@ class StripedHyena(nn.Module):
             from ..hyena_tables import mfma_operand_table
             f._mfma_tab = mfma_operand_table(f._poles, f._residues, f.D.data)
         return f._mfma_tab
-
-    def _mfma_pack(self, blk):
-        """(grouped projection weight, grouped bias, MFMA operand table, perm, inverse perm) of a Hyena block -- the group-major
-        path's pack (the channel-major path of hyena_ct.hip reads the projection weight as it is: _mfma_table alone)."""
-        f = blk.filter
-        if getattr(f, "_mfma", None) is None or f._mfma[0].device != blk.projections.weight.device:
-            from ..hyena_tables import group_permutation
-            w, b = blk.projections.weight.data, blk.projections.bias
-            perm = group_permutation(self.hidden_size, self.num_heads, w.device)
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(perm.numel(), device=perm.device)
-            f._mfma = (w[perm].contiguous(), None if b is None else b.data[perm].contiguous(), self._mfma_table(blk), perm, inv)
-        return f._mfma
 
     def _hyena_ct_ok(self, x2d, blk, B, T) -> bool:
         ops = self.ops
@@ -373,74 +371,32 @@ class StripedHyena(nn.Module):
             y = ops.hyena_decode_fused(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias,
                                        cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
                                        f._poles, f._residues, f.D, H)
-        elif mask is None and self._mfma_hyena_ok(B, T):
-            # the whole operator in ONE pass on the matrix cores (csrc/hyena_mfma.hip) -- scoring, and since round 3 cached
-            # prefill too (carry-in state + FIR history in, end state out).  It wants the projection's output columns grouped
-            # [16-channel group][x2 | x1 | v]: the projection GEMM writes that layout directly from a row-permuted copy of
-            # its weight (built once per layer, with the layer's MFMA operand table).
-            if self._hyena_ct_ok(x2d, blk, B, T):
-                # round 4, second form: z CHANNEL-MAJOR.  The pre-norm writes its rows in z^T's position order (HipOps.zt_layout: batch
-                # rows padded to a multiple of 64 positions, or -- T = 512 k + r, the bench shapes -- unpadded rows of 512 k positions with
-                # the last r tokens of every row in a tail block), the projection's dense layer runs with swapped operands (result = z^T, the weight as it is -- no
-                # regrouped copy) and the operator loads a lane's eight steps of a channel as 16 contiguous bytes straight into
-                # registers (csrc/hyena_ct.hip: no window in LDS); y BLOCKED as below.  Scoring and cached prefill alike.
-                table = self._mfma_table(blk)
-                xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
-                zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data, B, T)
-                yb = ops.yblk_empty(B * T, D, zt.device)
-                if cache is None:
-                    y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)
-                else:
-                    halo = s0 = None
-                    if have_state:              # continue a cached prefix with more than one token
-                        halo = cache.fir_state_dict[i].transpose(1, 2).contiguous()
-                        s0 = cache.state_dict[i]
-                    y, state = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
-                                            want_state=True, poles=f._poles, y_blk=yb)
-                    cache.fir_state_dict[i] = ops.zt_rows(zt, B, T, T - K1, K1).transpose(1, 2).contiguous()   # [B, 3D, 2]
-                    cache.state_dict[i] = state
-                self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias), None)
-                return
-            wg, bg, table, perm, inv = self._mfma_pack(blk)
+        elif mask is None and self._mfma_hyena_ok(B, T) and self._hyena_ct_ok(x2d, blk, B, T):
+            # the whole operator in ONE pass on the matrix cores (csrc/hyena_ct.hip) -- scoring and cached prefill (carry-in state + FIR
+            # history in, end state out) alike.
+            # z CHANNEL-MAJOR.  The pre-norm writes its rows in z^T's position order (HipOps.zt_layout: batch
+            # rows padded to a multiple of 64 positions, or -- T = 512 k + r, the bench shapes -- unpadded rows of 512 k positions with
+            # the last r tokens of every row in a tail block), the projection's dense layer runs with swapped operands (result = z^T, the weight as it is -- no
+            # regrouped copy) and the operator loads a lane's eight steps of a channel as 16 contiguous bytes straight into
+            # registers (no window in LDS); y BLOCKED: the operator stores whole cache lines and the output projection's dense layer
+            # gathers them -- no row-major y exists on this path.
+            table = self._mfma_table(blk)
+            xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
+            zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data, B, T)
+            yb = ops.yblk_empty(B * T, D, zt.device)
             if cache is None:
-                n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
-                if getattr(ops, "hyena_zg", False) and ops.linear_zg_ok(n1, wg):
-                    # scoring: the projection's dense layer writes z GROUP-MAJOR ([D / 16][B T][48]) and the operator reads one
-                    # contiguous stream per workgroup (no cache line shared between workgroups: DESIGN.md section 3)
-                    zg = ops.linear_zg(n1, wg, bg)
-                    if hasattr(ops, "hyena_cs") and getattr(ops, "hyena_cs_flag", False):
-                        # round 4: the channel-stationary kernel writes y BLOCKED (whole cache lines per store) and the output
-                        # projection's dense layer gathers it: no row-major y exists on this path
-                        y = ops.hyena_cs(zg, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=ops.yblk_empty(B * T, D, zg.device))
-                    else:
-                        y = ops.hyena_mfma_prefill(zg, f._fir_w, f.short_filter_bias, f.D, table, H, zg_shape=(B, T)).view(B * T, D)
-                else:
-                    z3 = ops.linear(n1, wg, bg).view(B, T, 3 * D)
-                    y = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H).view(B * T, D)
+                y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)
             else:
                 halo = s0 = None
-                if have_state:                  # continue a cached prefix with more than one token
-                    halo = cache.fir_state_dict[i].transpose(1, 2)[..., perm].contiguous()
+                if have_state:              # continue a cached prefix with more than one token
+                    halo = cache.fir_state_dict[i].transpose(1, 2).contiguous()
                     s0 = cache.state_dict[i]
-                n1 = None
-                if hasattr(ops, "hyena_cs") and getattr(ops, "hyena_zg", False):
-                    n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, self.eps)
-                if n1 is not None and ops.linear_zg_ok(n1, wg):
-                    # cached prefill on GROUP-MAJOR z too (round 4): the same projection launch and the same operator kernel as
-                    # scoring, plus the carried state in / the end state out
-                    zg = ops.linear_zg(n1, wg, bg)
-                    y3, state = ops.hyena_cs(zg, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
-                                             want_state=True, poles=f._poles, y_blk=ops.yblk_empty(B * T, D, zg.device))
-                    tail = ops.zg_rows(zg, B, T, T - K1, K1)
-                else:
-                    z3 = (ops.linear(n1, wg, bg) if n1 is not None
-                          else ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, wg, bg)).view(B, T, 3 * D)
-                    y3, state = ops.hyena_mfma_prefill(z3, f._fir_w, f.short_filter_bias, f.D, table, H, halo, s0=s0,
-                                                       want_state=True, poles=f._poles)
-                    tail = z3[:, -K1:, :]
-                y = y3 if y3.dim() == 4 else y3.view(B * T, D)
-                cache.fir_state_dict[i] = tail[..., inv].transpose(1, 2).contiguous()      # [B, 3D, 2], reference order
+                y, state = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, z_halo=halo, s0=s0,
+                                        want_state=True, poles=f._poles, y_blk=yb)
+                cache.fir_state_dict[i] = ops.zt_rows(zt, B, T, T - K1, K1).transpose(1, 2).contiguous()   # [B, 3D, 2]
                 cache.state_dict[i] = state
+            self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias), None)
+            return
         else:
             z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
             if mask is not None:

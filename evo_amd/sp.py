@@ -310,51 +310,52 @@ class SequenceParallelScorer:
         m, ops = self.m, self.m.ops
         D, H = m.hidden_size, m.num_heads
         f = blk.filter
-        # The single-pass matrix-core operator (csrc/hyena_mfma.hip) serves both stages when the shard fits its launch
-        # contract: stage 1 = its state-only walk (end state from a zero carry), stage 2 = the full pass seeded with the
-        # carried state.  It wants the projection in the GROUPED column order; every rank uses the same one, so the halo
-        # rows travel in that order too.  Other backends / shapes: the modal three-launch form (seg_state + carry_scan,
-        # then carry_add + apply).
-        # (the choice must be the SAME on every rank -- the halo rows travel in the projection's column order -- so it is made on
-        #  the shortest shard, the last one, not on this rank's own length)
-        #  the launches run per row group -- nb_max / nb_min rows -- on shards of Tl (every rank but the last) or t_min tokens:
-        #  the contract is evaluated on BOTH extremes, pure functions of (B, T, world), so every rank reaches the same verdict
+        # The single-pass matrix-core operator (csrc/hyena_ct.hip, the kernel of the scoring path) serves both stages when the shards fit
+        # its launch contract: stage 1 = its state-only walk (end state from a zero carry), stage 2 = the full pass seeded with the
+        # carried state, on CHANNEL-MAJOR z^T written by the projection's dense layer (the weight as it is: no regrouped copy per rank;
+        # the halo rows travel in the REFERENCE's column order).  Other backends / shapes: the modal three-launch form (seg_state +
+        # carry_scan, then carry_add + apply) on token-major z.
+        # The choice must be the SAME on every rank -- it is a function of (B, Tl, t_min = the last shard's length, world) only; the
+        # launches run per row group (nb_max / nb_min rows), so the contract is evaluated on BOTH extremes.
         t_min = T - (self.world - 1) * Tl
         G_ = max(1, min(self.row_groups, B))
         nb_max, nb_min = (B + G_ - 1) // G_, max(1, B // G_)
-        fast = getattr(ops, "hyena_mfma", False) and hasattr(ops, "hyena_mfma_state") \
-            and m._mfma_hyena_ok(nb_max, Tl) and m._mfma_hyena_ok(nb_min, t_min) \
-            and m._mfma_hyena_ok(nb_max, t_min) and m._mfma_hyena_ok(nb_min, Tl)
-        if fast:
-            w_p, b_p, table, _, _ = m._mfma_pack(blk)
+        ztm = getattr(ops, "hyena_mfma", False) and getattr(ops, "hyena_ct_flag", False) and hasattr(ops, "hyena_ct") \
+            and m._mfma_hyena_ok(nb_max, Tl) and m._mfma_hyena_ok(nb_min, t_min) and m._mfma_hyena_ok(nb_max, t_min) \
+            and m._mfma_hyena_ok(nb_min, Tl) and ops.zt_shape_ok(B, Tl, 3 * D, D) and ops.zt_shape_ok(B, t_min, 3 * D, D) and t_min >= 2
+        w_p, b_p = blk.projections.weight.data, (None if blk.projections.bias is None else blk.projections.bias.data)
+        table = m._mfma_table(blk) if ztm else None
+        if ztm:
+            n1 = None
+            xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, m.eps, B, Tloc)      # rows in z^T's position order
         else:
-            w_p, b_p, table = blk.projections.weight, blk.projections.bias, None
-        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
+            n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
         # (1) halo: the shard's last two rows go to the next rank.  They are projected on their own first (2B rows:
         #     the weight-streaming kernel) so that the send/recv flies under the big projection GEMM.
         halo, halo_w, tail = None, _Done(), None
         if self.world > 1:
             if Tloc >= 2:
-                rows = n1.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D)
+                if ztm:
+                    rows = ops.rmsnorm(x2d.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D).contiguous(), None, blk.pre_norm.scale, m.eps)
+                else:
+                    rows = n1.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D)
                 tail = ops.linear(rows, w_p, b_p).view(B, 2, 3 * D)
                 halo, halo_w = self._shift(tail)
             else:                                            # (last rank only, see check_geometry: nobody reads it)
-                halo, halo_w = self._shift(n1.new_zeros(B, 2, 3 * D))
-        # round 4: the fast path hands the operator its input GROUP-MAJOR ([D / 16][B Tloc][48], written that way by the projection's
-        # dense layer, as in scoring) and runs both stages on the channel-stationary kernel; the verdict is a function of
-        # (B, Tl, world) only -- evaluated on the longest shard, the same on every rank
-        zgm = fast and hasattr(ops, "hyena_cs") and ops.linear_zg_shape_ok(B * Tl, 3 * D, D) \
-            and ops.linear_zg_shape_ok(B * t_min, 3 * D, D)
-        if zgm:
-            z = ops.linear_zg(n1, w_p, b_p)                  # [D / 16, B Tloc, 48]
+                halo, halo_w = self._shift(x2d.new_zeros(B, 2, 3 * D))
+        if ztm:
+            z = ops.linear_t(xp, w_p, b_p, B, Tloc)          # z^T [blocks, 3 D, 256]
         else:
             z = ops.linear(n1, w_p, b_p).view(B, Tloc, 3 * D)
         if tail is not None:
             # the two rows the next rank convolves with came out of the weight-streaming kernel, this rank's own copy of them
             # out of the tile GEMM (another summation order: up to one bf16 ulp apart) -- use the SENT values here too, so
             # that both sides of a shard boundary see the same z
-            if zgm:
-                ops.zg_set_rows(z, B, Tloc, Tloc - 2, tail)
+            if ztm:
+                bb = torch.arange(B, device=z.device)[:, None].expand(B, 2)
+                tt = torch.arange(Tloc - 2, Tloc, device=z.device)[None, :].expand(B, 2)
+                pos = ops.zt_positions(B, Tloc, bb, tt).reshape(-1)
+                z[pos // 256, :, pos % 256] = tail.reshape(B * 2, 3 * D)
             else:
                 z[:, -2:, :] = tail
         halo_w.wait()
@@ -367,16 +368,14 @@ class SequenceParallelScorer:
         for g in range(G):
             b0, b1 = bounds[g], bounds[g + 1]
             hg = halo[b0:b1] if halo is not None else None
-            if zgm:
-                e_r = ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, poles=f._poles,
-                                   state_only=True, row0=b0 * Tloc)
-            elif fast:
-                e_r = ops.hyena_mfma_state(z[b0:b1], f._fir_w, f.short_filter_bias, table, H, f._poles, z_halo=hg)
+            if ztm:
+                e_r = ops.hyena_ct(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, poles=f._poles,
+                                   state_only=True, b_first=b0, b_total=B)
             else:
                 st1[g], e_r = ops.hyena_stage1(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, H, z_halo=hg)
             ends[g], works[g] = self._gather0(torch.view_as_real(e_r.to(torch.complex64)), async_op=True,
                                               name="state_allgather")
-        y = ops.yblk_empty(B * Tloc, D, z.device) if zgm else \
+        y = ops.yblk_empty(B * Tloc, D, z.device) if ztm else \
             (torch.empty(B, Tloc, D, dtype=z.dtype, device=z.device) if G > 1 else None)
         for g in range(G):
             b0, b1 = bounds[g], bounds[g + 1]
@@ -388,20 +387,17 @@ class SequenceParallelScorer:
                 idx = torch.arange(self.rank - 1, -1, -1, device=e.device)         # exponent index r-1-q
                 s0 = (pw[idx][:, None] * e).sum(0).to(torch.complex64)
             hg = halo[b0:b1] if halo is not None else None
-            if zgm:
-                ops.hyena_cs(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, s0=s0, row0=b0 * Tloc,
+            if ztm:
+                ops.hyena_ct(z, b1 - b0, Tloc, f._fir_w, f.short_filter_bias, table, H, z_halo=hg, s0=s0, b_first=b0, b_total=B,
                              y_blk=y, y_row0=b0 * Tloc)       # (blocked y, all row groups into one tensor)
                 continue
-            elif fast:
-                yg = ops.hyena_mfma_prefill(z[b0:b1], f._fir_w, f.short_filter_bias, f.D, table, H, hg, s0=s0)
-            else:
-                yg = ops.hyena_stage2(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1[g],
-                                      z_halo=hg, s0=s0)
+            yg = ops.hyena_stage2(z[b0:b1], f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H, st1[g],
+                                  z_halo=hg, s0=s0)
             if G > 1:
                 y[b0:b1] = yg
             else:
                 y = yg
-        if zgm:
+        if ztm:
             ops.linear_residual_yblk_(x2d, y, blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)
         else:
             ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)

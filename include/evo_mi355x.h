@@ -36,7 +36,9 @@ extern "C" {
  *   7: evo_hyena_ct (the same operator on channel-major z^T: no input window in LDS), evo_linear_t_mfma_bf16 (the projection with
  *      a transposed result) and evo_rmsnorm_rows_bf16 (RMSNorm with padded batch rows) added.
  *   8: evo_attn_fwd_causal_bf16 gained `vt_ws` (workspace for V^T: the round-5 prefill kernel of csrc/attn_w64.hip reads its V
- *      fragments from a transposed copy). */
+ *      fragments from a transposed copy); evo_hyena_mfma, evo_hyena_mfma_state, evo_hyena_mfma_zg, evo_hyena_cs_zg and
+ *      evo_linear_zg_mfma_bf16 REMOVED (the earlier forms of the single-pass Hyena operator and the group-major projection that
+ *      fed them: every caller is on evo_hyena_ct). */
 #define EVO_ABI_VERSION 8
 int evo_abi_version(void);
 
@@ -100,77 +102,43 @@ int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const 
 /* ---- Hyena operator, single-pass matrix-core form (scoring, cached prefill, sequence-parallel shards) -------
  * replaces the same reference functions as the three launches above (parallel_fir + compute_filter +
  * parallel_iir, and prefill_via_modal_fft for `s_out`)     [REF evo/configs/evo-1-8k-base_inference.yml:8,10,14,33,37;
- *                                                            evo/generation.py:117,152 for the cached form]
- * One launch, z read once, y written once: a workgroup owns 16 channels of one batch row and walks the sequence
- * in tiles of 512 steps; per tile the long convolution is a block-Toeplitz product + block aggregates on
- * v_mfma_f32_16x16x32_bf16 (operands split into bf16 hi + lo terms, fp32 accumulation), a Kogge-Stone scan of
- * the 16 blocks' modal states in fp32 and the carry product again on the bf16 matrix cores with hi/lo-split
- * states (csrc/hyena_mfma.hip).
- *   z      [B, T, 3D] bf16 in the GROUPED column order (evo_amd/hyena_tables.py: group_permutation)
- *   table  [D, 52, 64] u32: per-channel MFMA operand constants (hyena_tables.mfma_operand_table)
- *   z_halo [B, 2, 3D] bf16 (grouped order) or NULL, as above
+ *                                                            evo/generation.py:111-117,152 for the cached form]
+ * One launch, z read once, y written once (csrc/hyena_ct.hip; rounds 2-4 shipped three earlier forms of it -- token-major,
+ * group-major with channel-stationary waves -- which round 5 retired: this is the only single-pass kernel).  A wave owns two
+ * channels for a 512-step tile: its lanes' FIR outputs ARE the B operands of the block-Toeplitz MFMAs
+ * (v_mfma_f32_16x16x32_bf16, operands split into bf16 hi + lo terms, fp32 accumulation), the 16 blocks' modal states meet in a
+ * DPP scan in fp32, the carry product runs on the matrix cores with hi/lo-split states.
+ *   zt     CHANNEL-MAJOR z: [zt_pitch / 256][3 D][256] bf16, the projection's result TRANSPOSED and stored in blocks of 256
+ *          positions -- column c = h*3*hd + g*hd + j of z (the reference's order, no regrouping), position p at element
+ *          ((p / 256) * 3 D + c) * 256 + p % 256; written by evo_linear_t_mfma_bf16.  Batch row b, token t sits at position
+ *          zt_row0 + b * row_pitch + t.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into the
+ *          registers the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0,
+ *          zt_pitch % 256 == 0, zt_pitch * 3 D * 2 < 4 GiB, zt 16-byte aligned; positions between T and row_pitch may hold anything.
+ *   tail_T != 0 (the "tail form", T = 512 k + r with r <= 8: tail_T = 512 k): tokens t >= tail_T of batch row b sit at position
+ *          tail_pos0 + 8 b + (t - tail_T) instead (a tail block behind the main area, filled by the weight-streaming dense layer:
+ *          rows of 512 k positions need no padding and the projection no extra round of tiles; evo_amd/ops.py zt_layout).
+ *   z_halo [B, 2, 3 D] bf16 in the reference's column order (rows = steps -2, -1) or NULL
+ *   table  [D, 52, 64] u32: per-channel MFMA operand constants (evo_amd/hyena_tables.py mfma_operand_table; filter.D folded into
+ *          the block-Toeplitz diagonal)
  *   s0     [B, D, 8] c64 or NULL: modal state entering t = 0 (resumed prefill / sequence-parallel carry-in)
  *   s_out  [B, D, 8] c64 or NULL: state after t = T-1; needs `poles` [D, 8] c64 (fp32 pairs)
- *   no mask (padding_mask shapes take the three-launch form).
- * D = n_heads * 128 (any B, T). */
-int evo_hyena_mfma(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* dskip,
-                   const void* table, void* y, const float* s0, float* s_out, const float* poles,
-                   int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream);
-
-/* The same walk over z that writes NOTHING but the end state (no y): stage 1 of a sequence-parallel shard, whose end state
- * from a zero carry-in goes to the other ranks before anybody can finish its outputs (new; the reference has no multi-GPU
- * path).  Arguments as above; `s_out` and `poles` are required. */
-int evo_hyena_mfma_state(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table,
-                         const float* s0, float* s_out, const float* poles,
-                         int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream);
-
-/* evo_hyena_mfma on GROUP-MAJOR z: [D / 16 groups][B][T][48] bf16 (evo_linear_zg_mfma_bf16 writes it): every workgroup reads ONE
- * contiguous stream of whole cache lines instead of a 96-byte slice of every 6 D-byte row; with it the kernel uses its
- * bank-conflict-free plane layout (token-major z keeps the old one: DESIGN.md section 3).  Same arguments, same results bit for bit. */
-int evo_hyena_mfma_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* dskip,
-                      const void* table, void* y, const float* s0, float* s_out, const float* poles,
-                      int64_t B, int64_t T, int64_t D, int64_t n_heads, void* stream);
-
-/* The same operator -- HyenaInferenceEngine.parallel_fir + compute_filter + parallel_iir (+ prefill_via_modal_fft with `s_out`)
- *                                                      [REF evo/configs/evo-1-8k-base_inference.yml:8,10,14,33,37; evo/generation.py:111-114]
- * -- on group-major z with CHANNEL-STATIONARY waves (csrc/hyena_cs.hip, round 4): a wave owns 2 (or 4) channels of the group for the
- * whole 512-step tile, its lanes' FIR outputs ARE the B operands of the block MFMAs and its accumulators meet the FIR'd x2 of the same
- * lane, so no bf16 planes, no parked x2 and no fp32 y^T travel through LDS (hyena_mfma.hip: three LDS round trips per value).
- * z [D / 16][z_group_rows >= B T][48] bf16: batch row b of group g starts at row g * z_group_rows + b * T (so a caller can hand a
- * sub-range of batch rows of a larger tensor: z pointer advanced by b0 * T * 96 bytes, z_group_rows = the tensor's B_total * T).
- * z_halo [B, 2, 3 D] bf16 (grouped column order) or NULL; table = the int32 [D, 52, 64] operand table of evo_amd/hyena_tables.py
- * (filter.D folded into the block-Toeplitz diagonal); y [B, T, D] bf16; s0 / s_out [B, D, 8, 2] f32 or NULL; poles [D, 8, 2] f32
- * (needed with s_out).  state_only != 0: no y (may be NULL), only s_out -- stage 1 of a sequence-parallel shard.
- * y_blocked_rows != 0: y is written BLOCKED, [ceil(y_blocked_rows / 128)][D / 16][128][16] bf16 -- the [y_blocked_rows, D] matrix
- * with a group's 16 channels of 128 consecutive rows kept together (whole cache lines per store; evo_linear_xblk_mfma_bf16 reads
- * it); batch row b, token t is row y_row0 + b T + t of that matrix (y_row0 > 0: the row groups of a sequence-parallel shard write
- * into one tensor).
- * Same arithmetic as evo_hyena_mfma_zg (results agree to fp32 rounding of the block scan).  D == n_heads * 128. */
-int evo_hyena_cs_zg(const void* z, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
-                    const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
-                    int64_t z_group_rows, int64_t state_only, int64_t y_blocked_rows, int64_t y_row0, void* stream);
-
-/* The Hyena block's output projection on the blocked y of evo_hyena_cs_zg            [REF stripedhyena/model.py ParallelGatedConvBlock:
- * out_filter_dense]:  y [M, N] = x . w^T (+ bias [N]) (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense
- * layer of evo_linear_mfma_bf16 with other source addresses for its X tiles; M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128. */
-int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
-                              int64_t M, int64_t N, int64_t K, void* stream);
-
-/* The same operator once more -- same reference steps, same arithmetic, same y / state forms as evo_hyena_cs_zg -- on CHANNEL-MAJOR
- * z (csrc/hyena_ct.hip, round 4): zt [zt_pitch / 256][3 D][256] bf16 is the projection's result TRANSPOSED and stored in blocks of
- * 256 positions -- column c = h*3*hd + g*hd + j of z (the reference's order, no regrouping), position p at element
- * ((p / 256) * 3 D + c) * 256 + p % 256; written by evo_linear_t_mfma_bf16.  Batch row b, token t sits at position
- * zt_row0 + b * row_pitch + t.  A lane's eight steps of one channel are 16 consecutive bytes, loaded straight into the registers
- * the FIR reads: no window in LDS, no DMA, no bank conflicts.  row_pitch % 8 == 0, zt_row0 % 8 == 0 (16-byte loads),
- * zt_pitch % 256 == 0, zt_pitch * 3 D * 2 < 4 GiB, zt 16-byte aligned; positions between T and row_pitch may hold anything.
- * z_halo [B, 2, 3 D] bf16 in the REFERENCE's column order (rows = steps -2, -1) or NULL.
- * tail_T != 0 (the "tail form", T = 512 k + r with r <= 8: tail_T = 512 k): tokens t >= tail_T of batch row b sit at position
- * tail_pos0 + 8 b + (t - tail_T) instead (a tail block behind the main area, filled by the weight-streaming dense layer: rows of 512 k
- * positions need no padding and the projection no extra round of tiles; evo_amd/ops.py zt_layout); row_pitch >= tail_T then. */
+ *   state_only != 0: no y (may be NULL), only s_out -- stage 1 of a sequence-parallel shard, whose end state from a zero carry-in
+ *          goes to the other ranks before anybody can finish its outputs (new; the reference has no multi-GPU path)
+ *   y      [B, T, D] bf16, or with y_blocked_rows != 0 BLOCKED: [ceil(y_blocked_rows / 128)][D / 16][128][16] bf16 -- the
+ *          [y_blocked_rows, D] matrix with a group's 16 channels of 128 consecutive rows kept together (whole cache lines per
+ *          store; evo_linear_xblk_mfma_bf16 reads it); batch row b, token t is row y_row0 + b T + t of that matrix (y_row0 > 0:
+ *          the row groups of a sequence-parallel shard write into one tensor)
+ *   no mask (padding_mask shapes take the three-launch form).  D == n_heads * 128. */
 int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                  const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
                  int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t tail_T, int64_t tail_pos0, int64_t state_only,
                  int64_t y_blocked_rows, int64_t y_row0, void* stream);
+
+/* The Hyena block's output projection on the blocked y of evo_hyena_ct               [REF stripedhyena/model.py ParallelGatedConvBlock:
+ * out_filter_dense]:  y [M, N] = x . w^T (+ bias [N]) (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense
+ * layer of evo_linear_mfma_bf16 with other source addresses for its X tiles; M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128. */
+int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
+                              int64_t M, int64_t N, int64_t K, void* stream);
 
 /* The Hyena projection with a transposed result              [REF stripedhyena/model.py ParallelGatedConvBlock.forward: projections]:
  * zt [Mp / 256][N][256] bf16 = (x [Mp, K] . w [N, K]^T + bias [N])^T in blocks of 256 positions (an output tile of the kernel = one
@@ -272,16 +240,6 @@ int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const v
  * blocks of 64: rows 32 q .. 32 q + 31 of W1 followed by the same rows of W2 (q = 0 .. I / 32 - 1).
  * (2 I) % 256 == 0, K % 64 == 0, K >= 128, any M >= 1.  Returns -1 for an unsupported shape. */
 int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a, int64_t M, int64_t I, int64_t K, void* stream);
-
-/* ---- Hyena projection with a group-major result (prefill, scoring path) ---------------------------------------------
- * replaces the cuBLAS nn.Linear of ParallelGatedConvBlock's `projections` when its consumer is evo_hyena_mfma_zg
- *                                                     [REF stripedhyena/model.py ParallelGatedConvBlock.forward: z = self.projections(u)]
- * z [N / 48][Mtot][48] bf16 = (x [M, K] . w [N, K]^T + bias [N]), rows 0 .. M - 1 of every plane written (M <= Mtot); the rows of
- * w (columns of z) come in the grouped order of the single-pass Hyena operator ([16-channel group][x2 | x1 | v]).  Same kernel,
- * same accumulation and rounding as evo_linear_mfma_bf16: the values are those of its [M, N] result, only their place differs.
- * N % 256 == 0, N % 48 == 0, K % 64 == 0, K >= 128, Mtot * N * 2 < 4 GiB.  Returns -1 for an unsupported shape. */
-int evo_linear_zg_mfma_bf16(const void* x, const void* w, const void* bias, void* z, int64_t M, int64_t Mtot, int64_t N,
-                            int64_t K, void* stream);
 
 /* ---- Hyena mixer input of one decode step, fused ---------------------------------------------------------------
  * replaces pre-norm + projections GEMV + step_fir + step_iir of the single-token forward   [REF evo/generation.py:111-114,138-155]

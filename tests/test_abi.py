@@ -48,17 +48,11 @@ def test_argument_validation_needs_no_gpu():
     assert lib.evo_embed_bf16(None, None, None, 4, 16, 0, None, None) == -1            # empty vocabulary
     assert lib.evo_unembed_logprob_bf16(None, None, None, None, None, 8, 256, 4096, None) == -1    # V must be 512
     assert lib.evo_unembed_logprob_bf16(None, None, None, None, None, 8, 512, 100, None) == -1     # K % 32
-    assert lib.evo_hyena_mfma(None, None, None, None, None, None, None, None, None, None, 1, 64, 256, 3, None) == -1   # D != 128 * heads
-    assert lib.evo_hyena_mfma(None, None, None, None, None, None, None, None, None, None, 0, 64, 128, 1, None) == -1   # empty batch
-    assert lib.evo_hyena_mfma(None, None, None, None, None, None, None, None, None, None, 64, 131073, 4096, 32, None) == -1   # y beyond a 32-bit descriptor
     assert lib.evo_linear_mfma_bf16(None, None, None, None, None, 16, 256, 96, None) == -1           # K % 64
     assert lib.evo_linear_mfma_bf16(None, None, None, None, None, 16, 100, 64, None) == -1           # N % 256
     assert lib.evo_gelu_gate_bf16(None, None, 4, 12, None) == -1
     assert lib.evo_mlp_gate_mfma_bf16(None, None, None, 256, 100, 128, None) == -1                   # (2 I) % 256
     assert lib.evo_mlp_gate_mfma_bf16(None, None, None, 256, 128, 96, None) == -1                    # K % 64
-    assert lib.evo_linear_zg_mfma_bf16(None, None, None, None, 256, 256, 256, 128, None) == -1         # N % 48
-    assert lib.evo_linear_zg_mfma_bf16(None, None, None, None, 512, 256, 768, 128, None) == -1         # Mtot < M
-    assert lib.evo_hyena_mfma_zg(None, None, None, None, None, None, None, None, None, None, 1, 16, 200, 2, None) == -1   # D != 128 H
     one = ctypes.c_void_p(16)                                                                       # (a non-null, 16-byte aligned pointer value: never dereferenced)
     # evo_hyena_ct(..., B, T, D, H, zt_pitch, row_pitch, zt_row0, tail_T, tail_pos0, state_only, y_blocked_rows, y_row0, stream)
     assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 100, 0, 0, 0, 0, 0, 0, None) == -1   # row pitch % 8

@@ -13,8 +13,8 @@ What is compared with what (reference path: /root/reference/evo/scoring.py:80-84
  (b) prefix check at bench length: rows of the 8 x 8,193 HIP run (BASELINE configs[1]) vs the fp32 oracle on the
      first 2,049 tokens of the same row -- causality makes them comparable.
  (c) full-size operator checks against GPU restatements in fp64 (TEST INFRASTRUCTURE, rocFFT / eager matmul):
-     the SHIPPED Hyena operator kernels (hyena_ct on z^T in its tail and padded forms, hyena_cs on a group-major shard with
-     halo + carried state, and the modal three-launch path) vs an FFT long convolution at 8 x 8,193 x 4096,
+     the SHIPPED Hyena operator kernels (hyena_ct on z^T in its tail and padded forms and on a sequence-parallel shard with
+     halo + carried state in row groups, and the modal three-launch path) vs an FFT long convolution at 8 x 8,193 x 4096,
      1 x 131,073 x 4096 and 8 x 16,385 x 4096, and causal attention vs eager softmax attention at H = 32, T = 8,193 / 131,073.
 """
 import math
@@ -174,27 +174,27 @@ def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
     assert err <= floor                                       # never further from fp32 than eager bf16 is
 
 
-@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "group_major_hyena", "round3_hyena"])
+@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "attention_round4", "modal_hyena"])
 def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     """(b) BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
     oracle run on that prefix alone (the model is causal) -- end to end, and block by block with the engine's own
     block inputs (teacher-forced), which is the check that is not blurred by 32 layers of bf16 noise.
-    `gemm`: the default routing (round 4: every dense layer on the hand-written kernel of csrc/gemm.hip -- the Hyena projections
-    with a group-major result, the Hyena output projections gathering the operator's blocked y, the gated MLP's first half with
-    GELU * gate in the epilogue -- launch counts asserted: zero library GEMMs), and the three in-process A/B routings bench.py
-    times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt), `unfused` (dense layer +
-    gate kernel), `group_major_hyena` (ops.hyena_ct_flag = False: csrc/hyena_cs.hip on group-major z, the first form of this round)
-    and `round3_hyena` (also ops.hyena_cs_flag = False: csrc/hyena_mfma.hip, row-major y)."""
+    `gemm`: the default routing (every dense layer on the hand-written kernel of csrc/gemm.hip -- the Hyena projections with a
+    transposed result for hyena_ct, the Hyena output projections gathering the operator's blocked y, the gated MLP's first half with
+    GELU * gate in the epilogue; attention on attn_fwd_w64_kernel -- launch counts asserted: zero library GEMMs), and the in-process
+    A/B routings bench.py times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt),
+    `unfused` (dense layer + gate kernel), `attention_round4` (ops.attn_w64 = False: the 8-wave attention kernel of rounds 2-4) and
+    `modal_hyena` (ops.hyena_mfma = False: the three-launch modal Hyena kernels on token-major z)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P, row = 2049, 3
     ids = acgt_ids(8, 8192)
     m = full["m8"]
     ops = m.ops
-    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag, ops.hyena_ct_flag
+    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma
     ops.all_gemm_mfma = gemm != "library_l3"
     ops.mlp_gate_fused = gemm != "unfused"
-    ops.hyena_cs_flag = gemm != "round3_hyena"
-    ops.hyena_ct_flag = gemm not in ("round3_hyena", "group_major_hyena")
+    ops.attn_w64 = gemm != "attention_round4"
+    ops.hyena_mfma = gemm != "modal_hyena"
     if ops.timer is None:
         from evo_amd.ops import KernelTimer
         ops.timer = KernelTimer()
@@ -207,18 +207,21 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
         launches = {k_: n for k_, (n, _) in ops.timer.summary().items()}
     finally:
         m.block_taps = None
-        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.hyena_cs_flag, ops.hyena_ct_flag = was
+        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma = was
         ops.timer = None
     # the routing under test really ran (here `model(ids)` materialises logits through ops.linear: one more dense layer than a
     # scoring step, whose unembedding is fused into the tail kernel)
     print(f"[prefix {gemm}] launches: {launches}")
-    proj = "gemm_zt" if ops.hyena_ct_flag and gemm not in ("round3_hyena", "group_major_hyena") else "gemm_zg"
-    assert launches.get(proj, 0) == 29 and launches.get("hyena_mfma", 0) == 29 and launches.get("gemm_zg" if proj == "gemm_zt" else "gemm_zt", 0) == 0
+    if gemm == "modal_hyena":
+        assert launches.get("gemm_zt", 0) == 0 and launches.get("hyena_mfma", 0) == 0 and launches.get("hyena_apply", 0) == 29
+    else:
+        assert launches.get("gemm_zt", 0) == 29 and launches.get("hyena_mfma", 0) == 29 and launches.get("hyena_apply", 0) == 0
+    assert launches.get("attn_fwd", 0) == 3
     if gemm == "library_l3":
         assert launches.get("gemm", 0) >= 32 and launches.get("gemm_gate", 0) == 32
     elif gemm == "unfused":
         assert launches.get("gemm", 0) == 0 and launches.get("gemm_gate", 0) == 0 and launches.get("gelu_gate", 0) >= 32
-    else:                                                  # default / round3_hyena: 29 + 32 + 6 + 1 plain launches, 32 gated, no library
+    else:                                                  # 29 + 32 + 6 + 1 plain launches (modal_hyena: + 29 token-major projections), 32 gated, no library
         assert launches.get("gemm", 0) == 0 and launches.get("gemm_mfma", 0) >= 68 and launches.get("gemm_gate", 0) == 32
     assert logits.shape == (8, 8193, 512) and len(taps) == 33
     o = oracle_for(full, FULL, "fp32")
@@ -330,12 +333,13 @@ def test_hyena_operator_3x5003_padded_form_full_width_vs_fft():
     _check_hyena_fullsize(3, 5003, 24, 2e-5, "padded")
 
 
-def test_hyena_cs_shard_8x16385_full_width_with_halo_and_carry_vs_fft():
-    """BASELINE configs[3]: what ONE sequence-parallel rank runs per Hyena layer -- `hyena_cs_kernel` (csrc/hyena_cs.hip, C-ABI entry
-    evo_hyena_cs_zg) on a GROUP-MAJOR shard of 8 x 16,385 tokens at D = 4096 with the two halo rows of the left neighbour and a carried-in
-    modal state (evo_amd/sp.py: stage 2 of a shard; stage 1 = the state-only walk from a zero state is checked beside it) -- every output
-    and the end state vs the fp64 FFT restatement continued from the same halo / state."""
-    from evo_amd.hyena_tables import group_permutation, mfma_operand_table
+def test_hyena_ct_shard_8x16385_full_width_with_halo_and_carry_vs_fft():
+    """BASELINE configs[3]: what ONE sequence-parallel rank runs per Hyena layer (evo_amd/sp.py) -- `hyena_ct_kernel` on the z^T of a shard
+    of 8 x 16,385 tokens at D = 4096 (tail form: 16,385 = 512 x 32 + 1) with the two halo rows of the left neighbour and a carried-in
+    modal state, launched per ROW GROUP (b_first / b_total: two groups of four rows into one blocked y) as the scorer does; stage 1 =
+    the state-only walk from a zero state is checked beside it -- every output and the end state vs the fp64 FFT restatement continued
+    from the same halo / state."""
+    from evo_amd.hyena_tables import mfma_operand_table
     from evo_amd.ops import HipOps
     ops = HipOps()
     B, T, D = 8, 16385, 4096
@@ -352,20 +356,23 @@ def test_hyena_cs_shard_8x16385_full_width_with_halo_and_carry_vs_fft():
     del rfloor, sfloor
     bound = ry.abs() * 2 ** -8 + float(ry.abs().max()) * 2e-3
     table = mfma_operand_table(poles, res, dskip)
-    perm = group_permutation(D, H, z.device)
-    zg = z[..., perm].reshape(B * T, D // 16, 48).transpose(0, 1).contiguous()         # [G, B T, 48]: linear_zg's layout
-    halo_g = halo[..., perm].contiguous()
+    assert ops.zt_layout(B, T)[3] == 1                                          # tail form
+    zt = ops.zt_from_rows(z, B, T, pad_value=float("nan"))
     del z
-    s1 = ops.hyena_cs(zg, B, T, fir_w, fir_b, table, H, z_halo=halo_g, poles=poles, state_only=True)        # stage 1: end state from zero
-    yb, st = ops.hyena_cs(zg, B, T, fir_w, fir_b, table, H, z_halo=halo_g, s0=s0, want_state=True, poles=poles,
-                          y_blk=ops.yblk_empty(B * T, D, zg.device))                                         # stage 2: seeded pass
+    yb = ops.yblk_empty(B * T, D, zt.device)
+    s1, st = [], []
+    for b0 in (0, 4):
+        s1.append(ops.hyena_ct(zt, 4, T, fir_w, fir_b, table, H, z_halo=halo[b0:b0 + 4], poles=poles, state_only=True, b_first=b0, b_total=B))
+        st.append(ops.hyena_ct(zt, 4, T, fir_w, fir_b, table, H, z_halo=halo[b0:b0 + 4], s0=s0[b0:b0 + 4], want_state=True, poles=poles,
+                               b_first=b0, b_total=B, y_blk=yb, y_row0=b0 * T)[1])
+    s1, st = torch.cat(s1), torch.cat(st)
     yd = ops.yblk_to_rows(yb, B * T).view(B, T, D).double()
     err = (yd - ry).abs()
     rl2 = ((yd - ry).norm() / ry.norm()).item()
     srel = ((st.to(torch.complex128) - rst).abs().max() / rst.abs().max()).item()
     srel1 = ((s1.to(torch.complex128) - rst0).abs().max() / rst0.abs().max()).item()
-    print(f"[fft cross-check shard 8x16385, halo + carried state] hyena_cs: y rel-L2 {rl2:.3e} (eager-bf16 arithmetic {floor_rl2:.3e}), worst excess "
-          f"over the bf16 bound {(err - bound).max().item():.3e}, end-state rel {srel:.2e} (floor {floor_srel:.2e}), state-only walk {srel1:.2e}")
+    print(f"[fft cross-check shard 8x16385, halo + carried state, two row groups] hyena_ct: y rel-L2 {rl2:.3e} (eager-bf16 arithmetic {floor_rl2:.3e}), "
+          f"worst excess over the bf16 bound {(err - bound).max().item():.3e}, end-state rel {srel:.2e} (floor {floor_srel:.2e}), state-only walk {srel1:.2e}")
     assert torch.isfinite(yd).all() and (err <= bound).all()
     assert rl2 < 2e-3 and rl2 <= floor_rl2
     assert srel <= 2e-5 and srel <= floor_srel and srel1 <= 2e-5
@@ -519,3 +526,54 @@ def test_score_rel_distribution_64_sequences(full):
     print("[score distribution] engine:", " ".join(f"{x:.1e}" for x in rel.tolist()))
     assert rel.mean().item() <= 1.25e-3 and rel.mean().item() <= rel_flo.mean().item()
     assert rel.max().item() <= rel_flo.max().item()
+
+
+# ---- (f) the north-star tolerance on trained-like weights ------------------------------------------------------------------------
+def test_contractive_profile_logits_and_scores_vs_fp32_and_eager_bf16():
+    """North-star: "logits within 1e-3 relative of the reference".  On the default synthetic weights that sentence can be neither met nor
+    refuted (32 blocks that each re-write the stream amplify rounding noise until ANY bf16 evaluation, the reference's included, sits
+    0.1-0.2 rel-L2 from fp32 -- test (e) above judges the per-sequence score instead).  `profile="contractive"`
+    (evo_amd/synthetic.py: blocks 1.. change the stream by ~7 % of its norm, as trained residual stacks do; real checkpoints are not
+    reachable offline [REF evo/models.py:91-99]) removes the amplification.  16 BASELINE configs[0] sequences (1 x 512 nt) through the
+    engine, the oracle in fp32 and the oracle in its eager-bf16 mode (= the arithmetic the reference runs: /root/reference/evo/scoring.py:81-84
+    on a bf16 StripedHyena), oracles executed on the GPU by torch's eager kernels.  Reported and pinned: logits rel-L2 per sequence
+    and the score's relative error, engine and eager-bf16, both against fp32."""
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.synthetic import calibrate_contractive, synthetic_state_dict
+    m = StripedHyena(dict(FULL))
+    sd = synthetic_state_dict(m, seed=0, device=DEV, profile="contractive")
+    m.load_state_dict(sd, strict=True)
+    m.to_bfloat16_except_poles_residues()
+    m = m.to(DEV)
+    ids = acgt_ids(16, 512)
+    m.block_taps = []
+    try:
+        got = m(ids.to(DEV))[0].float().cpu()
+        taps = [t.float() for t in m.block_taps]
+    finally:
+        m.block_taps = None
+    ratios = [float((taps[i + 1] - taps[i]).norm() / taps[i].norm()) for i in range(32)]
+    print(f"[contractive] block update / stream norm: block 0 {ratios[0]:.2f}, blocks 1..31 min {min(ratios[1:]):.3f} max {max(ratios[1:]):.3f}")
+    assert 0.03 <= min(ratios[1:]) and max(ratios[1:]) <= 0.15
+    sdm = {k: v for k, v in m.state_dict().items()}
+    o32 = R.RefStripedHyena(R.RefConfig.from_dict(FULL), sdm, "fp32", device=DEV)
+    o16 = R.RefStripedHyena(R.RefConfig.from_dict(FULL), sdm, "bf16", device=DEV)
+    ref = o32(ids)[0].float().cpu()
+    flo = o16(ids)[0].float().cpu()
+    del o32, o16
+    assert ref.std() > 0.1                                                      # non-degenerate logits (SURVEY A.6)
+    rl = lambda a: ((a.double() - ref.double()).flatten(1).norm(dim=1) / ref.double().flatten(1).norm(dim=1))   # noqa: E731
+    e_eng, e_flo = rl(got), rl(flo)
+    s_ref, s_got, s_flo = score_of(ref, ids), score_of(got, ids), score_of(flo, ids)
+    r_eng, r_flo = (s_got - s_ref).abs() / s_ref.abs(), (s_flo - s_ref).abs() / s_ref.abs()
+    print(f"[contractive] logits std {ref.std().item():.2f}; logits rel-L2 vs fp32: engine mean {e_eng.mean():.3e} max {e_eng.max():.3e} | "
+          f"eager-bf16 reference arithmetic mean {e_flo.mean():.3e} max {e_flo.max():.3e}")
+    print(f"[contractive] score rel vs fp32: engine mean {r_eng.mean():.3e} max {r_eng.max():.3e} | eager-bf16 mean {r_flo.mean():.3e} max {r_flo.max():.3e} "
+          f"(north-star: 1e-3 relative -- {'met' if r_eng.max() <= 1e-3 else 'NOT met'} on the score by every sequence, "
+          f"{'met' if e_eng.max() <= 1e-3 else 'not met'} on the logits' rel-L2; a bf16 ulp is 3.9e-3)")
+    # the engine is at least as close to fp32 as the reference's own arithmetic, on every aggregate; and the amplification is gone
+    # measured (round 5, MI355X): logits rel-L2 engine 1.62e-2 / eager-bf16 1.94e-2 (64 bf16 roundings of the stream accumulate as
+    # sqrt(64) x 2e-3 -- no amplification left, and no bf16 pipeline gets below that); score rel engine mean 1.6e-4 max 5.5e-4, eager-bf16
+    # mean 1.5e-4 max 4.5e-4 (16 samples: the two are the same distribution)
+    assert e_eng.mean() <= e_flo.mean() and e_eng.max() <= 1.1 * e_flo.max() and e_eng.max() <= 2.5e-2
+    assert r_eng.mean() <= max(1.5 * r_flo.mean(), 3e-4) and r_eng.max() <= 1.0e-3        # the north-star's 1e-3, on every sequence

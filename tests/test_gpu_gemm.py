@@ -202,34 +202,6 @@ def test_mlp_gate_fused_is_the_unfused_arithmetic(M, I, K):
     print(f"[mlp_gate fused {M}x{I}x{K}] worst err / tol = {worst:.3f}")
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(256, 768, 128, True), (700, 768, 192, False), (4096 + 8, 3072, 512, True), (16384, 12288, 4096, True),
-                                        (65544, 12288, 4096, True)])
-def test_linear_zg_is_the_dense_layer_in_group_major_order(M, N, K, bias):
-    """evo_linear_zg_mfma_bf16 (the Hyena projection with a group-major result: z [N / 48][M][48]) against evo_linear_mfma_bf16:
-    the same kernel, the same accumulation -- the [M, N] result regrouped must be equal bit for bit; the BOS sliver (M % 256 <= 16
-    rows through the weight-streaming kernel) within a bf16 rounding."""
-    ops = _ops()
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
-    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if bias else None
-    was = ops.hyena_zg
-    ops.hyena_zg = True
-    try:
-        assert ops.linear_zg_ok(x, w)
-        z = ops.linear_zg(x, w, b)
-        again = ops.linear_zg(x, w, b)
-    finally:
-        ops.hyena_zg = was
-    assert z.shape == (N // 48, M, 48) and torch.equal(z, again)
-    want = ops.linear_mfma(x, w, b).view(M, N // 48, 48).transpose(0, 1)
-    r = ops._tail_rows(x, w)
-    assert torch.equal(z[:, : M - r], want[:, : M - r]), f"{int((z[:, : M - r] != want[:, : M - r]).sum())} elements differ"
-    if r:
-        d = (z[:, M - r:].double() - want[:, M - r:].double()).abs()
-        assert bool((d <= want[:, M - r:].double().abs() * 2.0 ** -7 + 2e-3).all())
-
-
 @pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1024, 4096, 4096), (65536 + 8, 4096, 4096), (768 + 200, 512, 256)])
 def test_output_projection_on_the_blocked_hyena_output_is_the_row_major_dense_layer(M, N, K):
     """evo_linear_xblk_mfma_bf16 (round 4): the Hyena block's output projection reads y in the BLOCKED layout the channel-stationary

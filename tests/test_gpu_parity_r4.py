@@ -178,7 +178,9 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
     del taps, oc
     assert not bad, bad[:12]
     # the end state sums 8,192 inputs x1 * v that carry the bf16 rounding of z: judged against what the reference's own arithmetic does
-    assert state_rel <= max(1.25 * state_floor, 4e-3) and fir_max <= 1.0 and kv_rel <= 4e-3, (state_rel, state_floor, fir_max, kv_rel)
+    # (FIR history = two bf16 rows of z per layer: an element on the other side of a rounding boundary is one ulp = up to 2^-7 |ref| off,
+    #  i.e. up to ~1.3 in units of the bound; anything beyond a single flip would show as >= 2)
+    assert state_rel <= max(1.25 * state_floor, 4e-3) and fir_max <= 1.35 and kv_rel <= 4e-3, (state_rel, state_floor, fir_max, kv_rel)
 
     # ---- end to end: the oracle's own cached path, fed the engine's tokens; the eager-bf16 restatement beside it ---------------
     def oracle_run(orc):
@@ -232,20 +234,20 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     ops = m.ops
     comm = _ThreadComm(world)
     rec = {r: [] for r in range(world)}                       # per rank: (z as the kernel got it, z_halo, s0, y) of Hyena layer 0
-    real_cs = ops.hyena_cs
+    real_ct = ops.hyena_ct                                    # (round 5: the shards run hyena_ct_kernel on channel-major z^T, like the scoring path)
 
-    def spy(zg, nb, tl, *a, **kw):
-        out = real_cs(zg, nb, tl, *a, **kw)
+    def spy(zt, nb, tl, *a, **kw):
+        out = real_ct(zt, nb, tl, *a, **kw)
         r = comm.local.rank
         if not kw.get("state_only", False) and len(rec[r]) < 2:        # layer 0 = the first two output launches of a rank (two row groups)
-            row0 = kw.get("row0", 0)
-            zt = ops.zg_rows(zg[:, row0:row0 + nb * tl, :], nb, tl, 0, tl).clone()        # token-major [nb, tl, 3 D], grouped column order
+            b0, bt = kw.get("b_first", 0), kw.get("b_total", None)
+            rows = ops.zt_rows(zt, b0 + nb if bt is None else bt, tl, 0, tl)[b0:b0 + nb].clone()   # token-major [nb, tl, 3 D], reference column order
             halo = kw.get("z_halo")
             yo = out[0] if isinstance(out, tuple) else out
             if yo.dim() == 4:                                 # blocked y (all row groups of the shard in one tensor): this launch's rows
                 y0 = kw.get("y_row0", 0)
                 yo = ops.yblk_to_rows(yo, y0 + nb * tl)[y0:]
-            rec[r].append((zt, None if halo is None else halo.clone(), kw.get("s0"), yo.clone()))
+            rec[r].append((rows, None if halo is None else halo.clone(), kw.get("s0"), yo.clone()))
         return out
 
     outs, errs = [None] * world, []
@@ -263,13 +265,13 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
             errs.append(e)
             comm.bar.abort()
 
-    ops.hyena_cs = spy
+    ops.hyena_ct = spy
     try:
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         [t.start() for t in th]
         [t.join(900) for t in th]
     finally:
-        del ops.hyena_cs                                       # (the instance attribute shadowed the method)
+        del ops.hyena_ct                                       # (the instance attribute shadowed the method)
     assert not errs, errs
     Tl = outs[0][0][0]
     assert Tl == 16385 and [o[0][2] - o[0][1] for o in outs] == [16385] * 7 + [16378]
@@ -305,7 +307,6 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
 
     # ---- shard 7's Hyena output of layer 0 (carry from 7 predecessors) vs the fp64 FFT long convolution over the WHOLE sequence
     assert all(len(rec[r]) == 2 for r in range(world)), {r: len(v) for r, v in rec.items()}
-    _, _, _, perm, inv = m._mfma_pack(m.blocks[0])
     f = m.blocks[0].filter
 
     heads = [0, 13, 31]
@@ -315,7 +316,7 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     t0 = time.time()
     worst_rl2 = worst_ex = 0.0
     for b in range(B):
-        zfull = torch.cat([rec[r][b][0][0][..., inv][:, cols] for r in range(world)], 0)          # [T, 3 * 384], reference column order
+        zfull = torch.cat([rec[r][b][0][0][:, cols] for r in range(world)], 0)          # [T, 3 * 384], reference column order
         assert zfull.shape == (T, 3 * 384)
         ry, _ = gpu_fft_hyena(zfull[None], f._fir_w[cols], f.short_filter_bias.data[cols], f._poles[chans], f._residues[chans],
                               f.D.data[chans], len(heads), want_state=False)

@@ -1,7 +1,7 @@
 """CPU: the blocked (matrix-core) form of the Hyena long convolution -- block Toeplitz + block aggregates + Kogge-Stone
 block scan + carry product, with the kernel's operand precisions (bf16 hi/lo data, bf16-split T0 / W, fp32 G / P, fp32
 accumulation; the carry product G . S with both operands bf16-split) -- emulated in torch and compared with the fp64 oracle.  This pins the MATH and the PRECISION of
-csrc/hyena_mfma.hip (constants from evo_amd/hyena_tables.py) independently of any GPU layout question."""
+csrc/hyena_ct.hip (constants from evo_amd/hyena_tables.py) independently of any GPU layout question."""
 import math
 
 import pytest

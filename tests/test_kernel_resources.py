@@ -1,6 +1,6 @@
 """Static resource checks of the hand-written kernels (CPU: hipcc cross-compiles gfx950 without a GPU).  A kernel that starts to spill
 VGPRs to scratch, or outgrows the LDS / register budget its launch bounds assume, still passes every numerical test -- it just runs at
-a fraction of its speed (csrc/hyena_cs.hip's four-wave form: 130 spilled registers, -15 %).  These are the budgets the measured
+a fraction of its speed (the retired csrc/hyena_cs.hip's four-wave form: 130 spilled registers, -15 %).  These are the budgets the measured
 numbers in DESIGN.md section 3 were taken with."""
 import os
 import re
@@ -38,7 +38,6 @@ def _metadata(src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,pattern,max_vgpr,max_lds", [
     ("hyena_ct.hip", "hyena_ct_kernel", 256, 64 * 1024),      # two waves per SIMD: 256 registers each; no input window: < 64 KB of LDS
-    ("hyena_cs.hip", "hyena_cs_kernel", 256, 160 * 1024),     # two waves per SIMD; two z windows + staging in LDS
 ])
 def test_hyena_kernels_fit_their_register_and_lds_budget(src, pattern, max_vgpr, max_lds):
     kernels = {k: v for k, v in _metadata(src).items() if pattern in k}
@@ -46,7 +45,7 @@ def test_hyena_kernels_fit_their_register_and_lds_budget(src, pattern, max_vgpr,
     for name, r in kernels.items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)        # no vector register reaches scratch memory
         assert r["vgpr"] <= max_vgpr and r["lds"] <= max_lds, (name, r)
-        # (scalar spills go to VGPR lanes -- v_writelane, no memory: the end-state forms park 10-23 wave-uniform values there, the scoring
-        #  form of hyena_cs two; hyena_ct's scoring form has none)
+        # (scalar spills go to VGPR lanes -- v_writelane, no memory: the end-state forms park 10-23 wave-uniform values there;
+        #  hyena_ct's scoring form has none)
         if "ILb0ELb0E" in name:
-            assert r["sgpr_spill"] <= (0 if "hyena_ct" in name else 4), (name, r)
+            assert r["sgpr_spill"] == 0, (name, r)

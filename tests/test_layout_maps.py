@@ -1,9 +1,10 @@
-"""CPU: the index maps the round-3 kernels rely on, restated in Python and checked exhaustively (no GPU, no library call).
+"""CPU: the index maps the kernels rely on, restated in Python and checked exhaustively (no GPU, no library call).
 
 * csrc/gemm.hip: the relabelling of W rows inside the LDS slab that makes a lane's accumulators of an n-tile pair eight
-  consecutive output columns; the chunk -> (group, place) map of the group-major epilogue; the gated-MLP weight regrouping.
-* csrc/hyena_mfma.hip: the two plane layouts as ONE formula (unit stride US, lo-term offset LO) -- every (channel, step, term)
-  gets its own bytes inside the channel's XTCH bytes, and the fp32 (y + x1v D)^T quads lie over exactly the bytes of their steps.
+  consecutive output columns; the gated-MLP weight regrouping; the X-tile gather from the Hyena operator's blocked y.
+* csrc/hyena_ct.hip: lane positions / history lanes / the z^T layout in its two forms.
+* csrc/attn_w64.hip: the key order of the S^T accumulator registers under the K-row swap, the V^T tile image and its DMA plan.
+(The maps of the retired csrc/hyena_mfma.hip / hyena_cs.hip -- plane layouts, window image, group-major chunks -- went with them in round 5.)
 """
 import itertools
 
@@ -26,18 +27,6 @@ def test_w_row_relabelling_is_a_permutation_and_gives_eight_consecutive_columns(
                 assert cols == list(range(wn_base + 32 * b + 8 * q, wn_base + 32 * b + 8 * q + 8)), (b, q, cols)
 
 
-def test_group_major_chunk_map():
-    """Epilogue mode 2: chunk cc (8 columns) of the grouped projection output -> group cc // 6, 16-byte place cc % 6 of its 96-byte
-    row; the kernel divides by a multiply-shift."""
-    for cc in range(8192):
-        grp = (cc * 10923) >> 16
-        assert grp == cc // 6 and 0 <= cc - 6 * grp < 6
-    # largest byte offset the kernel forms in 32 bits: (group * Mtot + m) * 96 + place * 16 at the largest supported problem
-    n_groups, mtot = 12288 // 48, 131073
-    assert ((n_groups - 1) * mtot + (mtot - 1)) * 96 + 5 * 16 < 0xfffffff0
-    assert mtot * 12288 * 2 < 0xfffffff0             # the descriptor's num_records
-
-
 def test_gate_weight_regrouping_puts_matching_columns_in_one_wave_tile():
     """pack_gate_weights + the relabelling: strip 2 p of a wave holds z1 and strip 2 p + 1 holds z2 of the same 32 gated columns."""
     I = 256                                          # inner size (a toy multiple of 128: one 256-row tile covers 128 gated columns)
@@ -56,94 +45,9 @@ def test_gate_weight_regrouping_puts_matching_columns_in_one_wave_tile():
                     assert [c for _, c in z1] == list(range(gated, gated + 8))
 
 
-def plane_byte(step, lo, US, LO):
-    return (step >> 3) * US + (step & 7) * 2 + lo * LO
-
-
-def quad_byte(q, US, LO):
-    return (q >> 1) * US + (q & 1) * LO
-
-
-def test_plane_layouts_are_one_formula():
-    for (US, LO, XTCH) in ((32, 16, 2064), (16, 1056, 2192)):
-        used = {}
-        for step, lo in itertools.product(range(512), (0, 1)):
-            b = plane_byte(step, lo, US, LO)
-            assert 0 <= b and b + 2 <= XTCH
-            for byte in (b, b + 1):
-                assert byte not in used, (US, step, lo, used.get(byte))
-                used[byte] = (step, lo)
-        assert len(used) == 2048                     # 512 steps x 2 terms x 2 bytes, no overlap
-        # the fp32 result quad q (steps 4 q .. 4 q + 3, 16 bytes) overwrites bytes of its OWN unit's operands only: unit u = q >> 1
-        # (8 steps) owns 16 bytes of hi terms and 16 bytes of lo terms -- stage 3's thread reads what stage 1's thread wrote
-        for q in range(128):
-            b = quad_byte(q, US, LO)
-            assert b % 16 == 0 and b + 16 <= XTCH
-            owners = {used[x][0] >> 3 for x in range(b, b + 16)}
-            assert owners == {q >> 1}, (US, q, owners)
-        assert XTCH % 16 == 0
-
-
-# ---- round 4: csrc/hyena_cs.hip and the blocked-X dense layer ----------------------------------------------------------------
-def test_hyena_cs_window_image_and_bank_spread():
-    """The LDS image of a tile's z window: 16 blocks of 32 rows x 96 B + a 16-byte pad, filled by 49 one-KiB DMA pieces (lane l of
-    piece p writes LDS byte 1024 p + 16 l).  Every (row, signal, quad) a lane reads must hold the stream bytes the kernel thinks it
-    holds; a ds_read_b64 of the 32 lanes of a group lands on all 64 banks twice (2-way: the floor for 8 bytes out of 16-byte granules)."""
-    import collections
-    BLKB = 32 * 96 + 16
-
-    def dma_off(o):                                       # hyena_cs.hip: dma_off[] (source byte of the lane's chunk within the tile)
-        blk, within = divmod(o, BLKB)
-        return 32 * 96 * blk + (within if within < 32 * 96 else 32 * 96 - 16)
-    src = {1024 * p + 16 * l: dma_off(1024 * p + 16 * l) for p in range(49) for l in range(64)}
-    for r in range(512):
-        for s in range(3):
-            for q4 in range(4):
-                a = r * 96 + (r >> 5) * 16 + 32 * s + 8 * q4
-                assert src[a & ~15] + (a & 15) == r * 96 + 32 * s + 8 * q4
-    assert max(src) + 16 <= 49 * 1024
-    for la in range(16):                                  # a lane's ten rows: two of history, eight of its own
-        for lq in range(4):
-            main = (32 * la + 8 * lq) * 96 + la * 16
-            hist = main - 192 if lq else (main - 192 - 16 if la else None)
-            for i in range(10):
-                r = 32 * la + 8 * lq + i - 2
-                if r < 0:
-                    continue                              # (block 0: the halo slot)
-                addr = (hist + i * 96) if i < 2 else main + (i - 2) * 96
-                assert addr == r * 96 + (r >> 5) * 16
-    for i in range(2, 10):
-        for grp in range(2):
-            banks = collections.Counter()
-            for lane in range(32 * grp, 32 * grp + 32):
-                la, lq = lane & 15, lane >> 4
-                a = (32 * la + 8 * lq) * 96 + la * 16 + (i - 2) * 96
-                for d in range(2):
-                    banks[(a // 4 + d) % 64] += 1
-            assert max(banks.values()) == 2
-
-
-def test_hyena_cs_row_permutation_of_the_operand_tables():
-    """T0 / G rows as hyena_cs.hip loads them: logical row 16 mt + la (la = 4 q + r) of the kernel = step 8 q + 4 mt + r of the block =
-    row 8 (q & 1) + 4 mt + r of the table's M tile q >> 1.  Then the accumulators of lane (block, lq) -- rows 4 lq + r of both M tiles --
-    are its own eight steps 8 lq + 4 mt + r, and the map is a permutation of the 32 steps."""
-    steps = []
-    for mt in range(2):
-        for la in range(16):
-            q, r = la >> 2, la & 3
-            src_mt, src_row = q >> 1, 8 * (q & 1) + 4 * mt + r
-            step = 16 * src_mt + src_row
-            assert step == 8 * q + 4 * mt + r
-            steps.append(step)
-    assert sorted(steps) == list(range(32))
-    for lq in range(4):
-        own = sorted(8 * lq + 4 * mt + r for mt in range(2) for r in range(4))
-        assert own == list(range(8 * lq, 8 * lq + 8))
-
-
 def test_blocked_y_layout_and_the_dense_layers_gather():
-    """y blocked = [row block of 128][K / 16 groups][128 rows][16 channels].  (1) the byte hyena_cs.hip stores row R, group cg at;
-    (2) HipOps.yblk_to_rows / zg_rows / zg_set_rows invert the layouts; (3) csrc/gemm.hip (XB): the lane that fills 16-byte granule
+    """y blocked = [row block of 128][K / 16 groups][128 rows][16 channels].  (1) the byte hyena_ct.hip stores row R, group cg at;
+    (2) HipOps.yblk_to_rows inverts the layout; (3) csrc/gemm.hip (XB): the lane that fills 16-byte granule
     s of LDS row r of an X slab (rows m0 .. m0 + 255, channels 64 k .. 64 k + 63) fetches exactly that row's channels 8 s' .. 8 s' + 7
     (s' = the swizzled granule), with voffset = lane part, soffset = m0 * K * 2 + k * 16,384."""
     import torch
@@ -176,14 +80,6 @@ def test_blocked_y_layout_and_the_dense_layers_gather():
                         row, ch = m0 + r0 + 32 * jj, 64 * k + 8 * xs                # what LDS row r0 + 32 jj, granule slot lane & 7 must hold
                         want = (((row // 128) * G + ch // 16) * (128 * 16) + (row % 128) * 16 + ch % 16) * 2
                         assert soff + voff == want, (m0, k, wave, lane, jj)
-    # group-major z helpers
-    B, T = 3, 5
-    zt = torch.arange(B * T * 3 * 32, dtype=torch.float32).view(B, T, 96)
-    zg = zt.view(B * T, 2, 48).transpose(0, 1).contiguous()
-    assert torch.equal(HipOps.zg_rows(zg, B, T, 3, 2), zt[:, 3:5])
-    z2 = torch.zeros_like(zg)
-    HipOps.zg_set_rows(z2, B, T, 0, zt)
-    assert torch.equal(z2, zg)
 
 
 def test_ct_lane_positions_history_lanes_and_zt_layout():
@@ -263,23 +159,54 @@ def test_ct_lane_positions_history_lanes_and_zt_layout():
                 assert Mp <= out < Mp + 16
 
 
-def test_rmsnorm_rows_workspace_is_per_thread_and_per_shape():
-    """HipOps._xpad_buffer: the same tensor for the same shape on one thread, a fresh zeroed one for another shape, and never the
-    tensor another thread is using."""
+def test_rmsnorm_rows_workspace_is_per_thread_and_per_layout():
+    """HipOps._xpad_buffer: the same tensor for the same (B, T) on one thread, a fresh zeroed one for another layout -- also one with the
+    SAME padded row count (1 x 513 in tail form, then 1 x 500 padded) --, and never the tensor another thread is using."""
     import threading
     import torch
     from evo_amd.ops import HipOps
     ops = HipOps.__new__(HipOps)                              # (no library needed for this helper)
     ops._xpad = threading.local()
-    a = ops._xpad_buffer(8, 16, "cpu")
-    assert a.shape == (8, 16) and a.dtype == torch.bfloat16 and bool((a == 0).all())
+    assert HipOps.zt_layout(1, 513)[2] == HipOps.zt_layout(1, 500)[2] == 512
+    a = ops._xpad_buffer(1, 513, 16, "cpu")
+    assert a.shape == (512 + 16, 16) and a.dtype == torch.bfloat16 and bool((a == 0).all())
     a.fill_(1.0)
-    assert ops._xpad_buffer(8, 16, "cpu") is a                # cached
-    b = ops._xpad_buffer(12, 16, "cpu")
-    assert b is not a and bool((b == 0).all())                # another shape: a new zeroed buffer ...
-    c = ops._xpad_buffer(8, 16, "cpu")
-    assert c is not a and bool((c == 0).all())                # ... and one shape at a time
+    assert ops._xpad_buffer(1, 513, 16, "cpu") is a           # cached
+    b = ops._xpad_buffer(1, 500, 16, "cpu")
+    assert b is not a and b.shape == a.shape and bool((b == 0).all())   # another layout with the same rows: a new zeroed buffer ...
+    c = ops._xpad_buffer(1, 513, 16, "cpu")
+    assert c is not a and bool((c == 0).all())                # ... and one layout at a time
     seen = []
-    t = threading.Thread(target=lambda: seen.append(ops._xpad_buffer(8, 16, "cpu")))
+    t = threading.Thread(target=lambda: seen.append(ops._xpad_buffer(1, 513, 16, "cpu")))
     t.start(); t.join()
     assert seen[0] is not c and bool((seen[0] == 0).all())    # another thread: its own buffer
+    ops.release_workspaces()
+    assert ops._xpad_buffer(1, 513, 16, "cpu") is not c
+
+
+def test_attn_w64_key_order_vt_image_and_dma_plan():
+    """csrc/attn_w64.hip, replayed on the host.  (1) K rows are read with bits 2 and 3 of the key index swapped; with the MFMA C/D layout
+    (accumulator register r of lane (col, half) = row (r & 3) + 8 (r >> 2) + 4 half) register r then holds key 16 (r >> 3) + 8 half +
+    (r & 7) of the 32-key half: the eight keys of a P^T fragment (registers 8 u .. 8 u + 7) are CONTIGUOUS, so a V^T fragment is one
+    16-byte read.  (2) V^T tile image [128 d][128 B]: chunk c of row d sits at slot c ^ ((d >> 1) & 7); the 16 lanes of every
+    ds_read_b128 lane group hit 16 distinct 16-byte bank windows.  (3) the DMA plan: piece j (8 rows), lane L writes LDS bytes
+    j * 1024 + 16 L = row 8 j + (L >> 3), slot L & 7, and must fetch chunk (L & 7) ^ ((row >> 1) & 7) of that row -- the kernel's
+    per-lane constant uses ((4 (wave & 1) + (L >> 4)) & 7) for every piece j = wave + 4 jj of the wave."""
+    swap = lambda m: (m & 0x13) | ((m & 4) << 1) | ((m & 8) >> 1)          # noqa: E731  (the kernel's `krow`)
+    assert sorted(swap(m) for m in range(32)) == list(range(32))
+    for half in (0, 1):
+        for r in range(16):
+            row = (r & 3) + 8 * (r >> 2) + 4 * half                          # accumulator row of register r
+            assert swap(row) == 16 * (r >> 3) + 8 * half + (r & 7)           # = the key that row's K fragment was read from
+    # K reads stay conflict-free: a b128 lane group reads 16 rows that are distinct mod 16 (rows of 272 bytes)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for g in groups:
+        assert len({swap(l) % 16 for l in g}) == 16
+        for chunk in range(8):                                              # V^T: slot16 = (d & 1) * 8 + (chunk ^ ((d >> 1) & 7))
+            assert len({((d & 1) * 8 + (chunk ^ ((d >> 1) & 7))) for d in g}) == 16
+    for wave in range(4):
+        for jj in range(4):
+            j = wave + 4 * jj
+            for L in range(64):
+                row = 8 * j + (L >> 3)
+                assert ((row >> 1) & 7) == ((4 * (wave & 1) + (L >> 4)) & 7)

@@ -54,18 +54,20 @@ def main():
             try:                                                   # single-pass matrix-core form of the same operator
                 from evo_amd.hyena_tables import mfma_operand_table
                 tab = mfma_operand_table(poles, res, dskip)
-                for _ in range(2):                                     # (random data: the column order does not matter here)
-                    ops.hyena_mfma_prefill(z, fir_w, fir_b, dskip, tab, H)
+                zt = ops.zt_from_rows(z, B, T)                         # (the layout the projection writes: csrc/hyena_ct.hip)
+                yb = ops.yblk_empty(B * T, D, dev)
+                for _ in range(2):
+                    ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=yb)
                 ops.timer = KernelTimer()
                 for _ in range(args.reps):
-                    ops.hyena_mfma_prefill(z, fir_w, fir_b, dskip, tab, H)
+                    ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=yb)
                 torch.cuda.synchronize()
                 ms = ops.timer.summary()["hyena_mfma"][1]
                 ops.timer = None
-                print(f"[{tag}] hyena_mfma B={B} T={T}: {ms:.3f}ms | {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of 8 TB/s")
+                print(f"[{tag}] hyena_ct B={B} T={T}: {ms:.3f}ms | {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of 8 TB/s")
             except Exception as e:  # noqa: BLE001
                 ops.timer = None
-                print(f"[{tag}] hyena_mfma B={B} T={T}: FAILED {type(e).__name__}: {e}")
+                print(f"[{tag}] hyena_ct B={B} T={T}: FAILED {type(e).__name__}: {e}")
             if args.only == "hyena" and args.fft:
                 # the north-star's FFT form as a DATA POINT: the long convolution alone (no FIR, no gates, no layout change) by
                 # rocFFT through torch.fft in fp32 -- rfft of x1*v [B, D, n], times the filter's spectrum, irfft.  n = 2T rounded

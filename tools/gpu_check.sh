@@ -25,15 +25,15 @@ head -14 $O/bench_131k_kernel_stats.txt
 # HBM-side traffic of the Hyena operator as the scoring path launches it (hyena_ct: channel-major z^T, blocked y): separate counter
 # passes (no trace domains beside --kernel-trace)
 cd /tmp
-timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zrd -o r -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zrd.log 2>&1
-timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zwr -o w -- python $R/tools/profile_hyena_zg.py > $R/$O/pmc_zwr.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_c[st]" > $O/hyena_ct_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zrd -o r -- python $R/tools/profile_hyena_ct.py > $R/$O/pmc_zrd.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $R/$O/pmc_zwr -o w -- python $R/tools/profile_hyena_ct.py > $R/$O/pmc_zwr.log 2>&1
+cd $R && (python tools/summarize_prof.py pmc $O/pmc_zrd; python tools/summarize_prof.py pmc $O/pmc_zwr) | grep -E "^kernel|hyena_ct" > $O/hyena_ct_pmc_traffic.txt; rm -rf $O/pmc_zrd $O/pmc_zwr
 cat $O/hyena_ct_pmc_traffic.txt
 # SQ counters of the same launches (instruction mix, LDS activity / bank conflicts, wait states)
 cd /tmp
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq1 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq1.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq2 -o s -- python $R/tools/profile_hyena_zg.py > $R/$O/sq2.log 2>&1
-cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_c[st]" > $O/hyena_ct_sq_counters.txt; rm -rf $O/sq1 $O/sq2
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq1 -o s -- python $R/tools/profile_hyena_ct.py > $R/$O/sq1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/sq2 -o s -- python $R/tools/profile_hyena_ct.py > $R/$O/sq2.log 2>&1
+cd $R && (python tools/summarize_prof.py pmc $O/sq1; python tools/summarize_prof.py pmc $O/sq2) | grep -E "^kernel|hyena_ct" > $O/hyena_ct_sq_counters.txt; rm -rf $O/sq1 $O/sq2
 cat $O/hyena_ct_sq_counters.txt | cut -c1-200
 # the same for a decode run (BASELINE configs[4] shape: 8,192-nt prompt, greedy): per-kernel times of the generation leg
 cd /tmp
