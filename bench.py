@@ -626,6 +626,37 @@ def bench_generation(device, prompt=8192, new=1024):
            "hbm_frac_with_kv": (12.906e9 + 3 * (prompt + new / 2) * 2 * 4096 * 2) / dec / 1e9 / HBM_PEAK_GBS,
            "top_k4_decode_ms_per_token": dec4 * 1e3,
            "graph_engaged": getattr(model, "decode_graph_replays", 0) > 0}
+    # ---- the semantic_design usage profile on the same 7B weights: many prompts x samples, continuous batching (evo_amd/pool.py)
+    # [REF semantic_design/semantic_design.py:271-360].  Tokens/s INCLUDES the prompts' prefills; a pooled step streams the weights
+    # once for all live slots, so the HBM fraction is weights x steps / time.
+    try:
+        from evo_amd.pool import DecodePool
+        rng = np.random.default_rng(4242)
+        pool_res = {}
+        for n_slots, n_prompts, n_samp in ((8, 8, 2), (32, 16, 4)):
+            prompts = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(512, 1025, size=n_prompts)]
+            pool = DecodePool(model, CharLevelTokenizer(512), n_slots=n_slots, top_k=4, top_p=1.0, temperature=0.7, device=device)
+            torch.manual_seed(0)
+            pool.generate(prompts[:2], n_tokens=8, n_sample_per_prompt=n_samp)            # warm-up: graph capture at this slot count
+            pool.stats = {"steps": 0, "prefills": 0, "tokens": 0}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            seqs, _, _ = pool.generate(prompts, n_tokens=128, n_sample_per_prompt=n_samp)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            n_tok = sum(len(x) for x in seqs)
+            pool_res[f"slots{n_slots}"] = {"tokens_per_s": n_tok / dtp, "generations": len(seqs), "new_tokens_each": 128,
+                                           "prompts": n_prompts, "prompt_nt": "512-1024", "pooled_steps": pool.stats["steps"],
+                                           "prefills": pool.stats["prefills"], "seconds": dtp,
+                                           "ms_per_pooled_step_incl_prefills": dtp / max(1, pool.stats["steps"]) * 1e3,
+                                           "hbm_frac_weights": 12.906e9 * pool.stats["steps"] / dtp / 1e9 / HBM_PEAK_GBS}
+            if hasattr(model, "release_decode_graph"):
+                model.release_decode_graph()
+            del pool
+        pool_res["single_stream_tokens_per_s"] = 1.0 / dec4
+        res["pool"] = pool_res
+    except Exception as e:  # noqa: BLE001
+        res["pool"] = {"error": f"{type(e).__name__}: {e}"}
     del model
     torch.cuda.empty_cache()
     return res

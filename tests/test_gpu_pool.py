@@ -20,15 +20,22 @@ PROMPTS = ["ACGTACGTAGCTAGCTAGCATCGATCGATGCATGCATGCATGACTAGCTAGCTAGCATGCATCAGTCA
            "TTTACGATTACAGATTACAGATTACATTT" * 5, "C", "GATTACAGATTCCCGGGAAATTT" * 3, "ACGT" * 40]
 
 
-@pytest.mark.parametrize("n_slots,use_graph", [(4, True), (3, False), (8, True)])
-def test_pool_logits_match_parallel_forward(n_slots, use_graph):
+# the 7B model's width (D = 4096, 32 heads, inner 10,928) at 4 layers: the pool's regime of the weight-streaming kernels -- M = 5 ... 8 rows
+# take the LDS-staged fused launches at D = 4096 only, M = 9 ... 16 the MFMA form -- is not reachable with the toy dimensions
+WIDE4 = dict(vocab_size=512, hidden_size=4096, num_layers=4, attn_layer_idxs=[1], num_attention_heads=32)
+
+
+@pytest.mark.parametrize("dims,n_slots,use_graph", [("toy", 4, True), ("toy", 3, False), ("toy", 8, True), ("d4096", 8, True), ("d4096", 12, True)])
+def test_pool_logits_match_parallel_forward(dims, n_slots, use_graph):
     from evo_amd.pool import DecodePool
     from evo_amd.scoring import prepare_batch
     from evo_amd.tokenizer import CharLevelTokenizer
     tok = CharLevelTokenizer(512)
-    cfgd = dict(SMALL4, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+    cfgd = dict(SMALL4 if dims == "toy" else WIDE4, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
     cfg, sd, m = build(cfgd)
-    oracle, oracle_bf16 = R.RefStripedHyena(cfg, sd, "fp64"), R.RefStripedHyena(cfg, sd, "bf16")
+    odev = None if dims == "toy" else DEV                       # (the wide oracles run on torch's eager GPU kernels: checker only)
+    osd = sd if odev is None else {k: v.to(DEV) for k, v in sd.items()}
+    oracle, oracle_bf16 = R.RefStripedHyena(cfg, osd, "fp64", device=odev), R.RefStripedHyena(cfg, osd, "bf16", device=odev)
     pool = DecodePool(m, tok, n_slots=n_slots, top_k=4, top_p=1.0, temperature=0.7, device=DEV, use_graph=use_graph)
     torch.manual_seed(0)
     n_tok = 24
@@ -45,11 +52,12 @@ def test_pool_logits_match_parallel_forward(n_slots, use_graph):
         want = full[P - 1: P - 1 + n_tok]
         got = pool.last_logits[j]
         worst = max(worst, ((got - want).norm() / want.norm()).item())
-        ref = oracle(full_ids.cpu())[0][0][P - 1: P - 1 + n_tok]              # fp64 oracle on the very same tokens
-        flo = oracle_bf16(full_ids.cpu())[0][0][P - 1: P - 1 + n_tok]
+        oid = full_ids.cpu() if odev is None else full_ids
+        ref = oracle(oid)[0][0][P - 1: P - 1 + n_tok].cpu()                   # fp64 oracle on the very same tokens
+        flo = oracle_bf16(oid)[0][0][P - 1: P - 1 + n_tok].cpu()
         worst_oracle = max(worst_oracle, rel_l2(got, ref))
         worst_floor = max(worst_floor, rel_l2(flo, ref))
-    print(f"[pool {n_slots} slots, graph={use_graph}] recorded logits vs the fp64 oracle: worst rel-L2 {worst_oracle:.3e} "
+    print(f"[pool {dims} {n_slots} slots, graph={use_graph}] recorded logits vs the fp64 oracle: worst rel-L2 {worst_oracle:.3e} "
           f"(eager-bf16 oracle {worst_floor:.3e}); vs the engine's parallel forward {worst:.3e}")
     assert worst_oracle < max(1.5 * worst_floor, 4e-3), (worst_oracle, worst_floor)
     assert worst < 2e-2, worst

@@ -14,6 +14,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=2)
 a = ap.parse_args()
 from evo_amd.ops import default_ops  # noqa: E402
-args = argparse.Namespace(steps_131k=a.steps, sp_timeout=600.0)
+args = argparse.Namespace(steps_131k=a.steps, sp_timeout=600.0, skip_ab=True, skip_sp_predict=True)
 out = bench.bench_131k(args, torch.device("cuda:0"), 0, 1, False, default_ops())
 print({k: out[k] for k in ("value", "ms_per_step") if k in out})
