@@ -21,9 +21,16 @@
 //     BEFORE the trip's barrier, under the previous trip's P.V MFMAs: with one wave per SIMD nobody else covers an LDS round trip
 //     at the head of a trip.  ONE barrier per tile;
 //   * the running max is DEFERRED per row: a row's reference point m only moves when the tile's scaled maximum exceeds it by more
-//     than W_THR (log2 units), otherwise P = 2^(s c - m) <= 2^W_THR is used as it is -- P, l and O are floating point with fp32 /
-//     bf16 exponent range, so a common factor of up to 2^W_THR costs no precision, and the O rescale (128 accumulator registers per
-//     lane) almost never runs after a row's first tiles instead of on most tiles of an 8k row.  The decision is PER ROW (rows that
+//     than W_THR (log2 units), otherwise P = 2^(s c - m) <= 2^W_THR is used as it is -- P, l and O are floating point with the
+//     fp32 / bf16 exponent range (2^127), so a common factor of up to 2^W_THR costs no precision (every rounding is relative), only
+//     W_THR bits of the 127 of overflow headroom: with W_THR = 32, l <= 2^32 T and |O| <= 2^32 sum |v| stay 70 binary orders below
+//     the fp32 limit at T = 131,073.  The O rescale is what the threshold buys off: 136 accumulator registers per lane live in
+//     AGPRs, a rescale is read - multiply - write of each (~400 instructions, about the cost of a whole trip).  The threshold was
+//     8 at first (the value the FlashAttention-3/4 papers use for fp16-range P): fine on N(0, 1) scores, but the MODEL's scores at
+//     block 8 have a standard deviation of 9.5 log2 units and reach +55 (tools/attn_instep_ab.py --model): a row's running maximum
+//     climbs ~19 units between its first tile and its last, 64 rows share a wave, and a rescale ran on every fifth trip at
+//     8 x 8,193 (5.74 ms against 4.78 ms on N(0, 1) inputs of the same shape; profiles/r05_attn_w64_model_scores.txt).  At 32 a
+//     row sets its reference point on its first tile and keeps it.  The decision is PER ROW (rows that
 //     do not move get alpha = 1 exactly), so a row's arithmetic never depends on which other rows share its wave: outputs stay
 //     bit-identical across query offsets / launch geometries (tests/test_gpu_fullsize.py).  W_THR = 0 is the textbook update;
 //   * query blocks are aligned to the END of the query range (block 0 is the short one).  T = 2^k + 1 (a BOS token in front of 2^k
@@ -55,7 +62,7 @@
 #define W_VBASE (W_NK * W_KSTAGE)           // 69,632
 #define W_LDS (W_VBASE + W_NV * W_VSTAGE)   // 118,784 B
 #ifndef W_THR
-#define W_THR 8.0f                          // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
+#define W_THR 32.0f                         // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
 #endif
 #ifndef W_VD
 #define W_VD 4                              // V^T fragments read ahead of their MFMAs (5+: the register file spills into AGPR copies)

@@ -397,6 +397,38 @@ def test_attention_outlier_scores(ops):
     assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
 
 
+def test_attention_reference_point_moves_several_times_in_one_row(ops):
+    """The 64-rows-per-wave kernel keeps a row's reference point until a tile's largest exponent exceeds it by W_THR = 32 log2 units
+    (csrc/attn_w64.hip); a staircase of spikes 1.5 x, 3 x, 5 x, 8 x |q|^2 (steps of 24-49 units, one per key tile and later) walks the
+    rescale path four times in the same row, a -5 x spike on the row's FIRST key starts it 81 units below, and the neighbours in the
+    wave stay put (alpha = 1 exactly)."""
+    B, H, T = 1, 2, 900
+    q = bf(torch.randn(B, T, H, 128, generator=gen(124)))
+    k = bf(torch.randn(B, T, H, 128, generator=gen(125)))
+    v = bf(torch.randn(B, T, H, 128, generator=gen(126)))
+    for key, mul in ((100, 1.5), (300, 3.0), (500, 5.0), (700, 8.0)):
+        k[0, key, 0] = q[0, 850, 0] * mul
+    k[0, 0, 1] = q[0, 640, 1] * -5.0
+    k[0, 600, 1] = q[0, 640, 1] * 4.0
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
+    ref = R.op_attention(q, k, v, 0)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
+    assert_close_bf16(o[:, 850], ref[:, 850], rl2=4e-3, atol=2e-2)                  # the staircase row itself
+    assert_close_bf16(o[:, 640], ref[:, 640], rl2=4e-3, atol=2e-2)
+
+
+def test_attention_wide_scores_like_the_models_block_8(ops):
+    """Scores with a standard deviation of ~9 log2 units (q, k of rms 2.5: what the synthetic 7B model hands block 8,
+    tools/attn_instep_ab.py --model): softmax rows are dominated by a handful of keys, the running maximum climbs ~20 units along a
+    row.  Every output row against the fp64 oracle."""
+    B, H, T = 1, 2, 2049
+    q = bf(torch.randn(B, T, H, 128, generator=gen(127)) * 2.5)
+    k = bf(torch.randn(B, T, H, 128, generator=gen(128)) * 2.5)
+    v = bf(torch.randn(B, T, H, 128, generator=gen(129)))
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
+    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+
+
 def test_attention_4k_causal(ops):
     B, H, T = 1, 2, 4099
     q = bf(torch.randn(B, T, H, 128, generator=gen(27)))
