@@ -371,7 +371,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nt", type=int, default=8192)
     ap.add_argument("--skip-131k", action="store_true")
-    ap.add_argument("--skip-ab", action="store_true", help="skip the in-process A/B legs (library_gemm_l3, mlp_gate_unfused, attention_round4_kernel): "
+    ap.add_argument("--skip-ab", action="store_true", help="skip the in-process A/B legs (library_gemm_l3, mlp_gate_unfused, norm_unfused, attention_round4_kernel): "
                                                           "the profile runs want the headline step's kernels only")
     ap.add_argument("--skip-sp-predict", action="store_true", help="skip the stub-communicator rank of configs[3] (scaling_131k_predicted)")
     ap.add_argument("--skip-cpu", action="store_true")
@@ -503,6 +503,29 @@ def main():
             out["mlp_gate_unfused"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             ops.mlp_gate_fused = True
+    # ------------------------------------------------------------------ the same step with the 65 separate RMSNorm passes (rounds 1-4)
+    if n_gpus == 1 and getattr(ops, "fuse_norm", False) and not args.skip_ab:
+        try:
+            ops.fuse_norm = False
+            with torch.inference_mode():
+                dt7 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+                ops.timer = KernelTimer()
+                scoring_step(model, ids)
+                torch.cuda.synchronize()
+                k7 = ops.timer.summary()
+                ops.timer = None
+            out["norm_unfused"] = {"value": B * nt / (dt7 / 3), "unit": "nt/s", "ms_per_step": dt7 / 3 * 1e3, "steps": 3,
+                                   "rmsnorm_launches": k7.get("rmsnorm", (0, None))[0], "rmsnorm_avg_ms": k7.get("rmsnorm", (0, None))[1],
+                                   "rmsnorm_launches_headline": kernels.get("rmsnorm", {}).get("launches_per_step"),
+                                   "rms_finalize_launches_headline": kernels.get("rms_finalize", {}).get("launches_per_step"),
+                                   "note": "ops.fuse_norm = False in the same process: every RMSNorm as its own pass over the stream (a normalised copy "
+                                           "written and read back) instead of a row factor in the epilogue of the dense layer that consumes it, with the "
+                                           "statistic from the epilogue of the dense layer that wrote the stream (csrc/gemm.hip NF)"}
+        except Exception as e:  # noqa: BLE001
+            out["norm_unfused"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.fuse_norm = True
+            ops.timer = None
     # ------------------------------------------------------------------ the same step with the round-2..4 attention kernel
     if n_gpus == 1 and getattr(ops, "attn_w64", False) and not args.skip_ab:
         try:
@@ -776,6 +799,20 @@ def bench_131k(args, device, rank, world, dist_on, ops):
         finally:
             ops.timer = None
             ops.attn_w64 = True
+    if world == 1 and getattr(ops, "fuse_norm", False) and not getattr(args, "skip_ab", False):
+        try:                                              # the same 131k step with the 65 separate RMSNorm passes (two steps, the second timed)
+            ops.fuse_norm = False
+            with torch.inference_mode():
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                res["norm_unfused"] = {"ms_per_step": (time.perf_counter() - t0) * 1e3}
+        except Exception as e:  # noqa: BLE001
+            res["norm_unfused"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.fuse_norm = True
     if world == 1 and "attn_fwd" in ks:
         fl = 4 * D * T * T / 2
         res["kernels"]["attn_fwd"]["tflops"] = fl / (ks["attn_fwd"][1] * 1e-3) / 1e12

@@ -180,6 +180,55 @@ extern "C" int evo_rmsnorm_rows_bf16(void* x, const void* bias, const void* scal
     return rmsnorm_launch(x, bias, scale, out, M, D, eps, T, Tp, Tm, tail0, stream);
 }
 
+// The RMSNorm factor 1 / (rms(x_row) + eps) as a vector, for the dense layers that take the norm in their epilogue (csrc/gemm.hip, NF):
+// rows [0, M_main) from the partial sums of squares the stream-writing dense layers emit (ss [n_strips][ss_ld] fp32, added in strip
+// order: bit-reproducible), rows [M_main, M) -- the sliver the weight-streaming kernel wrote -- from x itself, one wave per row.  Same
+// arithmetic as rmsnorm_kernel's `inv` [REF stripedhyena/layers.py RMSNorm.forward].
+__global__ __launch_bounds__(256) void rms_finalize_kernel(const float* __restrict__ ss, int n_strips, int64_t ss_ld, const uint4* __restrict__ x,
+                                                           int64_t M_main, int64_t M, int nvec, float eps, float inv_sqrt_d,
+                                                           float* __restrict__ rstd, int main_blocks) {
+    if ((int)blockIdx.x < main_blocks) {
+        const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (m >= M_main) return;
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= n_strips; k += 8) {                  // eight independent requests in flight, added in strip order
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p[e] = ss[(int64_t)(k + e) * ss_ld + m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += p[e];
+        }
+        for (; k < n_strips; ++k) s += ss[(int64_t)k * ss_ld + m];
+        rstd[m] = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t row = M_main + ((int64_t)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const uint4* xr = x + row * nvec;
+    float s = 0.f;
+    for (int idx = lane; idx < nvec; idx += 64) {
+        float f[8];
+        unpack8(xr[idx], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(f[e], f[e], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) rstd[row] = 1.0f / (sqrtf(s) * inv_sqrt_d + eps);
+}
+
+extern "C" int evo_rms_finalize_f32(const float* sumsq, int64_t n_strips, int64_t ss_ld, const void* x, int64_t M_main, int64_t M, int64_t D,
+                                    float eps, float* rstd, void* stream) {
+    if (M <= 0 || M_main < 0 || M_main > M || D <= 0 || D % 8 != 0 || !rstd || (M_main > 0 && (!sumsq || n_strips <= 0 || ss_ld < M_main))
+        || (M_main < M && !x)) return -1;
+    const int main_blocks = (int)((M_main + 255) / 256);
+    const int tail_blocks = (int)((M - M_main + 3) / 4);
+    hipLaunchKernelGGL(rms_finalize_kernel, dim3((unsigned)(main_blocks + tail_blocks)), dim3(256), 0, (hipStream_t)stream, sumsq, (int)n_strips,
+                       ss_ld, (const uint4*)x, M_main, M, (int)(D / 8), eps, 1.0f / sqrtf((float)D), rstd, main_blocks);
+    return evo_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------- rope
 // qkv [B,T,3,H,hd]; one thread rotates 8 pairs (i..i+7, i+hd/2..) of one (b,t,q|k,h) row.
 __global__ __launch_bounds__(256) void rope_kernel(uint4* __restrict__ qkv, const float4* __restrict__ cos_t,

@@ -43,6 +43,12 @@ struct GemmArgs {
     const unsigned char* x; const unsigned char* w; const uint16_t* bias; const uint16_t* res; uint16_t* y;
     int64_t M; int N; int K;
     int tiles_n; int n_tiles; int tiles_m; int group_m;
+    // RMSNorm folded into the dense layers around it (round 5; persistent kernel only, see gemmr_bf16_kernel's NF parameter)
+    const float* rs = nullptr;               // SCALE: 1 / (rms + eps) per token row, applied to the accumulators in the epilogue
+    float* ss = nullptr;                     // STATS: partial sums of squares of the stored rows, [N / 128 strips][ss_ld] fp32
+    int64_t ss_ld = 0;
+    int64_t w_rows = 0;                      // MODE 3 + SCALE: rows of the token matrix (the kernel's "W" operand): B T
+    int tm_tiles = 0, row_skip = 0;          // MODE 3 + SCALE: a batch row = tm_tiles column tiles; its tokens start row_skip rows further per batch row
 };
 
 template <bool BIAS, bool RES>
@@ -351,9 +357,25 @@ static_assert(!GE_FULL || GE_ORDER == 1, "GE_FULL pairs the strips of GE_ORDER 1
 //   [row block of 128][K / 16 groups][128 rows][16 channels] bf16 -- a 64-channel slab of a row is four 32-byte pieces 4 KiB apart
 //   instead of one 128-byte piece; only the DMA's SOURCE addresses change (the lane that fills granule s of LDS row r fetches
 //   32-byte piece s >> 1, half s & 1), the k-step is 16 KiB instead of 128 B; the tile origin m0 * K * 2 is the same number.
-template <bool BIAS, bool RES, int MODE, bool XB = false>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; (2: retired with csrc/hyena_cs.hip in round 5);
+// NF (round 5): the RMSNorm passes around the dense layers, folded into their epilogues [REF stripedhyena/model.py: pre_norm / post_norm of
+//   every block; layers.py RMSNorm].  The reference writes a normalised copy n = bf16(g * x / (rms(x) + eps)) of the residual stream and
+//   multiplies it by the next layer's weight; here the layer that WRITES the stream also emits the statistic, and the layer that consumes it
+//   reads the stream itself:  W n = rstd_row * ((W diag(g)) x)  -- the scale vector folded into a copy of the weight (bf16(W g): one rounding of
+//   the weight instead of one of the activation), the row factor applied to the fp32 accumulators before bias / gate / the one rounding.
+//   NF & 1, STATS (RES launches): the rounded rows this tile stores are squared and summed per row over the wave's 128 columns
+//     (a lane holds 32 values of its row per m tile; two cross-lane steps join the four column groups) -> ss[n0 / 128 + wn][m]:
+//     evo_rms_finalize_f32 adds the N / 128 partials in a fixed order (no atomics: bit-reproducible).  ~520 VALU per lane and tile under
+//     the stores the epilogue is paced by.
+//   NF & 2, SCALE (launches without a residual): the token's factor rs[row] multiplies the accumulators.  Tokens run along the LANES
+//     in modes 0 / 1 (eight values per lane and tile: one per m tile) and along the REGISTERS in mode 3 (the swapped launch: 32 values per
+//     lane, the eight columns of its four strips).  Mode 3 also reads its token rows from the residual stream itself: z^T position
+//     p = b Tm + t is row p + b row_skip of x (tail form of z^T: rows of Tm = T - row_skip positions, a tile never straddles two batch rows).
+template <bool BIAS, bool RES, int MODE, bool XB = false, int NF = 0>   // MODE 0: y [M, N]; 1: gated MLP, a [M, N / 2]; (2: retired with csrc/hyena_cs.hip in round 5);
                                                             // 3: y [M, N] with the bias indexed by ROW (the swapped-operand launch: evo_linear_t_mfma_bf16)
 __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
+    constexpr bool STATS = (NF & 1) != 0, SCALE = (NF & 2) != 0;
+    static_assert(!STATS || (RES && MODE == 0), "the statistic rides on the launches that write the residual stream");
+    static_assert(!SCALE || !RES, "the row factor belongs to the launches that read the normalised stream");
     constexpr uint32_t XSTEP = XB ? 16384u : (uint32_t)(GBK * 2);   // bytes from one k-step's X slab to the next
     __shared__ __attribute__((aligned(16))) unsigned char smem[G_NSLOT * G_SLAB];   // the ONLY __shared__ object
     const int tid = threadIdx.x;
@@ -401,6 +423,12 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
         n0 = tn * GBN;
     };
 
+    // MODE 3 + SCALE: first row of the token matrix behind column origin n0 (a multiple of 256 positions)
+    auto src_row = [&](int n0) -> uint32_t {
+        if constexpr (MODE == 3 && SCALE) return (uint32_t)n0 + (uint32_t)((n0 / GBN) / a.tm_tiles) * (uint32_t)a.row_skip;
+        else return (uint32_t)n0;
+    };
+
     // ---- DMA plan: a slab is 32 one-KiB pieces (8 rows of 128 B each); wave w moves pieces w, w + 4, ..., w + 28.  The LDS
     //      side of a DMA is lane-linear (M0 + 16 lane), so the swizzle is applied to the source: the lane that fills granule
     //      slot s of row r fetches granule s ^ (r & 7) of that row (a fragment read touches 16 consecutive rows x 4 granules:
@@ -424,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     const uint64_t xa64 = (uint64_t)a.x, wa64 = (uint64_t)a.w;
     const g_u32x4 rx = {(uint32_t)xa64, (uint32_t)(xa64 >> 32) & 0xffffu,
                         (uint32_t)((XB ? (a.M + 127) / 128 * 128 : a.M) * (int64_t)kb), 0x00020000u};
-    const g_u32x4 rw = {(uint32_t)wa64, (uint32_t)(wa64 >> 32) & 0xffffu, (uint32_t)((int64_t)a.N * kb), 0x00020000u};
+    const g_u32x4 rw = {(uint32_t)wa64, (uint32_t)(wa64 >> 32) & 0xffffu, (uint32_t)((MODE == 3 && SCALE ? a.w_rows : (int64_t)a.N) * kb), 0x00020000u};
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t lds_dma = lds0 + wave * 1024;                 // + slot * G_SLAB + jj * 4096
 
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
         int64_t m0; int n0;
         tile_origin(t_first, m0, n0);
         fxs = (uint32_t)(m0 * kb);
-        fws = (uint32_t)n0 * kb;
+        fws = src_row(n0) * kb;
     }
     auto fetch_advance = [&]() {                                 // (prologue only; past the last stage: stay)
         if (f_k + 1 < nk) { ++f_k; fxs += XSTEP; fws += GBK * 2; }
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
             int64_t m0; int n0;
             tile_origin(t_first + f_i * t_step, m0, n0);
             fxs = (uint32_t)(m0 * kb);
-            fws = (uint32_t)n0 * kb;
+            fws = src_row(n0) * kb;
         }
     };
     // Inside the stream the cursor moves WITHOUT branches (a taken branch in the middle of the MFMA stream is an instruction
@@ -458,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
             int64_t m0; int n0;
             tile_origin(t_first + (f_i + 1) * t_step, m0, n0);
             nx0 = (uint32_t)(m0 * kb);
-            nw0 = (uint32_t)n0 * kb;
+            nw0 = src_row(n0) * kb;
         }
     };
     // The step itself is written as pieces of two or three scalar instructions, one piece per MFMA gap (GR_GAP): a one-wave-
@@ -495,6 +523,8 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     const uint32_t ep_voff_f = (uint32_t)((wm * 128 + (l15 & 7)) * ldy + wn * 128 + 8 * lq + 32 * (l15 >> 3)) * 2u;
     const uint32_t ep_boff = (uint32_t)(wn * 128 + 8 * lq) * 2u;        // bias: this lane's eight columns within a strip of the tile
     const uint32_t ep_rboff = (uint32_t)(wm * 128 + l15) * 2u;           // MODE 3 (row bias): this lane's row within the tile, m tile 0
+    const uint32_t ep_rsoff = (uint32_t)(wm * 128 + l15) * 4u;           // SCALE, modes 0 / 1, and STATS: this lane's row within the tile (fp32 per row), m tile 0
+    const uint32_t ep_rsoff3 = (uint32_t)(wn * 128 + 8 * lq) * 4u;       // SCALE, mode 3: this lane's eight columns (= tokens) within a strip of the tile
     // GATE: the output is [M, N / 2]; a wave's 128 tile columns = two gated strips of 32 columns = one 128-byte line per row
     const int ep_gn = a.N >> 1;
     const uint32_t ep_voff_g = (uint32_t)((wm * 128 + (l15 & 7)) * ep_gn + wn * 64 + 8 * lq + 32 * (l15 >> 3)) * 2u;
@@ -655,6 +685,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                 const uint64_t y64 = (uint64_t)(a.y + m0 * ep_gn);
                 const g_u32x4 yd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu, (uint32_t)(rows_ok * ep_gn * 2), 0x00020000u};
                 g_u32x4 ost[8], gq[2];
+                float rsj[8];                                      // SCALE: 1 / (rms + eps) of this lane's row in each of the eight m tiles
+                if constexpr (SCALE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(rsj[j]) : "v"(ep_rsoff), "s"(a.rs + m0 + 16 * j) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsj[0]), "+v"(rsj[1]), "+v"(rsj[2]), "+v"(rsj[3]), "+v"(rsj[4]), "+v"(rsj[5]),
+                                 "+v"(rsj[6]), "+v"(rsj[7]) :: "memory");
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -669,6 +707,10 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(z2[4 + r]) : "a"(acc[4 * pp + 3][j][r]));
                         }
                         GR_ZERO1(4 * pp, j); GR_ZERO1(4 * pp + 1, j); GR_ZERO1(4 * pp + 2, j); GR_ZERO1(4 * pp + 3, j);
+                        if constexpr (SCALE) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { z1[e] *= rsj[j]; z2[e] *= rsj[j]; }
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) {
                             const uint32_t u1 = pack_bf2(z1[e], z1[e + 1]), u2 = pack_bf2(z2[e], z2[e + 1]);     // the dense layers' bf16 outputs
@@ -707,6 +749,26 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
 #define GE_LOAD(U) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rr[(U) % GE_NR]) : "v"(ep_voff), "s"(rd), "s"(GE_SOFF(U)) : "memory")
             g_u32x4 rr[GE_NR], bq[4], ost[8], o_even;
             uint32_t rbq[8];                                     // MODE 3: the bias of this lane's row in each of the eight m tiles
+            float rsj[8];                                        // SCALE, mode 0: the factor of this lane's row in each of the eight m tiles
+            g_u32x4 rsq[4][2];                                   // SCALE, mode 3: the factors of the lane's eight columns (tokens) of every strip, as raw fp32
+            if constexpr (SCALE && MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(rsj[j]) : "v"(ep_rsoff), "s"(a.rs + m0 + 16 * j) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsj[0]), "+v"(rsj[1]), "+v"(rsj[2]), "+v"(rsj[3]), "+v"(rsj[4]), "+v"(rsj[5]),
+                             "+v"(rsj[6]), "+v"(rsj[7]) :: "memory");
+            }
+            if constexpr (SCALE && MODE == 3) {
+                const float* rs0 = a.rs + src_row(n0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rsq[b][0]) : "v"(ep_rsoff3), "s"(rs0 + b * 32) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rsq[b][1]) : "v"(ep_rsoff3), "s"(rs0 + b * 32 + 4) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsq[0][0]), "+v"(rsq[0][1]), "+v"(rsq[1][0]), "+v"(rsq[1][1]), "+v"(rsq[2][0]),
+                             "+v"(rsq[2][1]), "+v"(rsq[3][0]), "+v"(rsq[3][1]) :: "memory");
+            }
+            float ssq = 0.f, sst[4];                             // STATS: the running sum of squares of this lane's row in m tile j; stored totals
             if (BIAS && MODE != 3) {                             // the lane's eight columns of every strip
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
@@ -747,6 +809,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                 // the next tile's zeros, here: the epilogue runs at the pace of its stores (~270 cycles per store instruction and
                 // wave, whatever it carries), the eight writes are free; behind the loop they cost 1.4 k cycles per tile
                 GR_ZERO1(2 * b, j); GR_ZERO1(2 * b + 1, j);
+                if constexpr (SCALE && MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= rsj[j];
+                }
+                if constexpr (SCALE && MODE == 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= __uint_as_float(rsq[b][e >> 2][e & 3]);
+                }
                 if (BIAS && MODE != 3) {
                     v[0] += bf_lo(bq[b][0]); v[1] += bf_hi(bq[b][0]); v[2] += bf_lo(bq[b][1]); v[3] += bf_hi(bq[b][1]);
                     v[4] += bf_lo(bq[b][2]); v[5] += bf_hi(bq[b][2]); v[6] += bf_lo(bq[b][3]); v[7] += bf_hi(bq[b][3]);
@@ -764,6 +834,27 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
                 // the one rounding
                 g_u32x4 o;
                 o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); o[2] = pack_bf2(v[4], v[5]); o[3] = pack_bf2(v[6], v[7]);
+                if constexpr (STATS) {
+                    // squares of the ROUNDED values (what the next RMSNorm reads from memory); unit order u = 4 j + b: the four units of
+                    // an m tile are consecutive, one running sum is live
+                    static_assert(GE_ORDER == 1, "the statistic closes an m tile at b == 3");
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float lo_ = bf_lo(o[d]), hi_ = bf_hi(o[d]);
+                        ssq = fmaf(lo_, lo_, ssq);
+                        ssq = fmaf(hi_, hi_, ssq);
+                    }
+                    if (b == 3) {
+                        // the row's other three column groups sit in lanes l15 + 16, + 32, + 48
+                        float t_ = ssq + __uint_as_float((uint32_t)__builtin_amdgcn_ds_swizzle((int)__float_as_uint(ssq), 0x401f));   // xor 16
+                        t_ += __shfl_xor(t_, 32);
+                        sst[j & 3] = t_;
+                        // every lane group stores the same total to the same address (one instruction either way)
+                        const float* sp_ = a.ss + ((int64_t)(n0 / 128 + wn) * a.ss_ld + m0 + 16 * j);
+                        asm volatile("global_store_dword %0, %1, %2" :: "v"(ep_rsoff), "v"(sst[j & 3]), "s"(sp_) : "memory");
+                        ssq = 0.f;
+                    }
+                }
 #if GE_FULL
                 // A store instruction costs the wave ~270 cycles whatever it carries (measured: 16 rows x 64 B and 16 rows x 32 B
                 // alike) -- it is paid per row segment.  So two strips are stored together as WHOLE 128-byte lines, 8 rows per
@@ -796,6 +887,7 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" :: "v"(ost[k]));     // (the last eight quads stay distinct, too)
+            if constexpr (STATS) asm volatile("" :: "v"(sst[0]), "v"(sst[1]), "v"(sst[2]), "v"(sst[3]));
             GR_STAMP(8);                                         // (accumulator reads, packing, stores)
 #undef GE_LOAD
 #undef GE_NR
@@ -819,8 +911,20 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
 
 extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                                     int64_t M, int64_t N, int64_t K, void* stream) {
+    return evo_linear_mfma_nf_bf16(x, w, bias, residual, y, nullptr, nullptr, 0, M, N, K, stream);
+}
+
+// The same dense layer with the RMSNorm around it folded in (gemmr_bf16_kernel, NF): `row_scale` [ceil(M / 256) * 256] fp32 multiplies the
+// accumulators of row m before the bias (the consumer of a normalised stream: w is then W diag(g), no residual); `sumsq`
+// [N / 128][ss_ld] fp32 (ss_ld >= ceil(M / 256) * 256) receives the sums of squares of the stored rows per 128-column strip (the
+// producer of the stream: residual required).  Both need the persistent form's shape contract (K >= 128, operands < 4 GiB).
+extern "C" int evo_linear_mfma_nf_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                                       const float* row_scale, float* sumsq, int64_t ss_ld, int64_t M, int64_t N, int64_t K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || N > 0x7fffffff / 2) return -1;
+    if ((row_scale && (residual || sumsq)) || (sumsq && (!residual || ss_ld < (M + GBM - 1) / GBM * GBM))) return -1;
+    if ((row_scale || sumsq) && !(K >= 2 * GBK && M * K * 2 < 0xffffffffll && N * K * 2 < 0xffffffffll)) return -1;
     GemmArgs a;
+    a.rs = row_scale; a.ss = sumsq; a.ss_ld = ss_ld;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias;
     a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
     a.M = M; a.N = (int)N; a.K = (int)K;
@@ -845,6 +949,16 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
             return n < 8 ? 8 : n;
         }();
         const dim3 gridp((unsigned)n_cu), block4(256);
+        if (row_scale) {
+            if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 0, false, 2>), gridp, block4, 0, st, a);
+            else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 0, false, 2>), gridp, block4, 0, st, a);
+            return evo_launch_status();
+        }
+        if (sumsq) {
+            if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true, 0, false, 1>), gridp, block4, 0, st, a);
+            else hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, false, 1>), gridp, block4, 0, st, a);
+            return evo_launch_status();
+        }
         if (bias && residual) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true, 0>), gridp, block4, 0, st, a);
         else if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 0>), gridp, block4, 0, st, a);
         else if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0>), gridp, block4, 0, st, a);
@@ -863,11 +977,19 @@ extern "C" int evo_linear_mfma_bf16(const void* x, const void* w, const void* bi
 // out_filter_dense].  M % 256 == 0 (the caller peels the BOS sliver), K % 64 == 0, K >= 128.
 extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
                                          int64_t M, int64_t N, int64_t K, void* stream) {
+    return evo_linear_xblk_mfma_nf_bf16(x_blk, w, bias, residual, y, nullptr, 0, M, N, K, stream);
+}
+
+// ... and with the sums of squares of the stored rows (see evo_linear_mfma_nf_bf16; residual required when sumsq is given)
+extern "C" int evo_linear_xblk_mfma_nf_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
+                                            float* sumsq, int64_t ss_ld, int64_t M, int64_t N, int64_t K, void* stream) {
+    if (sumsq && (!residual || ss_ld < M)) return -1;
     if (M <= 0 || M % GBM != 0 || N <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || K < 2 * GBK || N > 0x7fffffff / 2) return -1;
     if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
     a.x = (const unsigned char*)x_blk; a.w = (const unsigned char*)w; a.bias = (const uint16_t*)bias;
     a.res = (const uint16_t*)residual; a.y = (uint16_t*)y;
+    a.ss = sumsq; a.ss_ld = ss_ld;
     a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)(M / GBM);
@@ -882,6 +1004,11 @@ extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const
         return n < 8 ? 8 : n;
     }();
     const dim3 gridp((unsigned)n_cu), block4(256);
+    if (sumsq) {
+        if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true, 0, true, 1>), gridp, block4, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, true, 1>), gridp, block4, 0, (hipStream_t)stream, a);
+        return evo_launch_status();
+    }
     if (bias && residual) hipLaunchKernelGGL((gemmr_bf16_kernel<true, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
     else if (residual) hipLaunchKernelGGL((gemmr_bf16_kernel<false, true, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
     else if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 0, true>), gridp, block4, 0, (hipStream_t)stream, a);
@@ -893,11 +1020,19 @@ extern "C" int evo_linear_xblk_mfma_bf16(const void* x_blk, const void* w, const
 // never reaches memory [REF stripedhyena/layers.py ParallelGatedMLP.forward].  w12g = the rows of [W1; W2] regrouped as blocks
 // of 64: 32 rows of W1 followed by the same 32 rows of W2 (evo_amd/ops.py pack_gate_weights), 2 I rows in all.
 extern "C" int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a_out, int64_t M, int64_t I, int64_t K, void* stream) {
+    return evo_mlp_gate_mfma_nf_bf16(x, nullptr, w12g, a_out, M, I, K, stream);
+}
+
+// ... with the post-mixer RMSNorm folded in: x = the residual stream itself, row_scale [ceil(M / 256) * 256] = 1 / (rms + eps) per row,
+// w12g = the regrouped rows of [W1 diag(g); W2 diag(g)] (see evo_linear_mfma_nf_bf16)
+extern "C" int evo_mlp_gate_mfma_nf_bf16(const void* x, const float* row_scale, const void* w12g, void* a_out, int64_t M, int64_t I, int64_t K,
+                                         void* stream) {
     const int64_t N = 2 * I;
     if (M <= 0 || I <= 0 || K <= 0 || N % GBN != 0 || K % GBK != 0 || K < 2 * GBK || N > 0x7fffffff / 2) return -1;
     if (M * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w12g; a.bias = nullptr; a.res = nullptr; a.y = (uint16_t*)a_out;
+    a.rs = row_scale;
     a.M = M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / GBN);
     a.tiles_m = (int)((M + GBM - 1) / GBM);
@@ -911,7 +1046,8 @@ extern "C" int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a_o
         n &= ~7;
         return n < 8 ? 8 : n;
     }();
-    hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 1>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+    if (row_scale) hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 1, false, 2>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 1>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }
 
@@ -924,11 +1060,25 @@ extern "C" int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a_o
 // the same products, one rounding).  Mp % 256 == 0 (the caller pads: every row of x is computed), N % 256 == 0, K % 64 == 0, K >= 128.
 extern "C" int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N, int64_t K,
                                       void* stream) {
+    return evo_linear_t_mfma_nf_bf16(x, nullptr, w, bias, zt, Mp, N, K, Mp, Mp, 0, stream);
+}
+
+// ... with the block's pre-norm folded in: x = the residual stream [x_rows, K] in (batch row, token) order, w = W diag(g), row_scale
+// [x_rows] = 1 / (rms + eps) per row; position p = b Tm + t of z^T (Mp = B Tm positions, Tm % 256 == 0) is row p + b row_skip of x -- the
+// tail form of z^T (HipOps.zt_layout: Tm = T - row_skip), whose tail tokens the caller projects separately.  row_scale == NULL:
+// the plain launch (x_rows = Tm = Mp, row_skip = 0).
+extern "C" int evo_linear_t_mfma_nf_bf16(const void* x, const float* row_scale, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N,
+                                         int64_t K, int64_t x_rows, int64_t Tm, int64_t row_skip, void* stream) {
+    if (row_scale) {
+        if (Tm <= 0 || Tm % GBN != 0 || Mp % Tm != 0 || row_skip < 0 || row_skip > 0x7fff || x_rows < Mp + (Mp / Tm - 1) * row_skip
+            || x_rows * K * 2 >= 0xffffffffll) return -1;
+    } else if (x_rows != Mp || Tm != Mp || row_skip != 0) return -1;
     if (Mp <= 0 || N <= 0 || K <= 0 || Mp % GBN != 0 || N % GBM != 0 || K % GBK != 0 || K < 2 * GBK || Mp > 0x7fffffff / 2) return -1;
     if (Mp * K * 2 >= 0xffffffffll || N * K * 2 >= 0xffffffffll) return -1;
     GemmArgs a;
     a.x = (const unsigned char*)w; a.w = (const unsigned char*)x; a.bias = (const uint16_t*)bias; a.res = nullptr; a.y = (uint16_t*)zt;
     a.M = N; a.N = (int)Mp; a.K = (int)K;
+    a.rs = row_scale; a.w_rows = x_rows; a.tm_tiles = (int)(Tm / GBN); a.row_skip = (int)row_skip;
     a.tiles_n = (int)(Mp / GBN);
     a.tiles_m = (int)(N / GBM);
     a.group_m = (a.tiles_m >= 32 ? 8 : 4);      // (column tiles per raster group: see tile_origin, MODE 3)
@@ -941,6 +1091,11 @@ extern "C" int evo_linear_t_mfma_bf16(const void* x, const void* w, const void* 
         n &= ~7;
         return n < 8 ? 8 : n;
     }();
+    if (row_scale) {
+        if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 3, false, 2>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 3, false, 2>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
+        return evo_launch_status();
+    }
     if (bias) hipLaunchKernelGGL((gemmr_bf16_kernel<true, false, 3>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemmr_bf16_kernel<false, false, 3>), dim3((unsigned)n_cu), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();

@@ -42,6 +42,11 @@ _SIGNATURES = {
     "evo_linear_t_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_linear_xblk_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_linear_mfma_nf_bf16": ([_PTR] * 7 + [_I64] * 4 + [_PTR], _c.c_int),
+    "evo_linear_xblk_mfma_nf_bf16": ([_PTR] * 6 + [_I64] * 4 + [_PTR], _c.c_int),
+    "evo_mlp_gate_mfma_nf_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_linear_t_mfma_nf_bf16": ([_PTR] * 5 + [_I64] * 6 + [_PTR], _c.c_int),
+    "evo_rms_finalize_f32": ([_PTR, _I64, _I64, _PTR, _I64, _I64, _I64, _F32, _PTR, _PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -53,7 +58,7 @@ _SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 8          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 9          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):
@@ -169,6 +174,9 @@ class HipOps:
         self.attn_gemm_mfma = True
         # prefill attention on the 64-rows-per-wave kernel of round 5 (csrc/attn_w64.hip); False: the 8-wave kernel of rounds 2-4 (bench A/B leg)
         self.attn_w64 = True
+        # round 5: the RMSNorm passes of prefill-sized batches ride in the epilogues of the dense layers around them (csrc/gemm.hip, NF;
+        # False = the separate rmsnorm launches: bench.py's A/B leg, the routing test)
+        self.fuse_norm = True
         # all_gemm_mfma = False puts the plain dense layers (l3, the unembedding of model(ids)) back on hipBLASLt through torch.addmm:
         # the library is 1-3 % faster on l3's shape (K = 11,008; profiles/r03_gemm_notes.txt) -- bench.py times that leg beside the headline
         self.all_gemm_mfma = True
@@ -589,6 +597,111 @@ class HipOps:
             tail = y_blk[nb0:].permute(0, 2, 1, 3).reshape(-1, K)[:r].contiguous()
             self.linear_residual_(res[Mf:], tail, w, bias=bias)
         return res
+
+    # ---- RMSNorm folded into the dense layers around it (csrc/gemm.hip NF; include/evo_mi355x.h "RMSNorm folded ...") -----------------
+    @staticmethod
+    def fold_norm_scale(w: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        """W diag(g) as a bf16 copy (fp32 product, one rounding): the weight the norm-consuming launches multiply the RAW stream by."""
+        return (w.float() * g.float()[None, :]).to(torch.bfloat16).contiguous()
+
+    def nf_shape_ok(self, M: int, N: int, K: int) -> bool:
+        """Shapes whose main rows the persistent dense layer takes with the norm folded in (sliver rows <= 16 or none)."""
+        r = M % 256
+        Mm = M - r if 1 <= r <= 16 else M
+        return (self.fuse_norm and self.all_gemm_mfma and M >= 512 and N % 256 == 0 and K % 64 == 0 and K >= 128
+                and Mm * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mm * N * 2 < 0xffffffff)
+
+    def _nf_main_rows(self, M: int) -> int:
+        r = M % 256
+        return M - r if 1 <= r <= 16 else M
+
+    def rms_finalize(self, ss: Optional[torch.Tensor], x: torch.Tensor, M_main: int, eps: float) -> torch.Tensor:
+        """rstd [M rounded up to 256] fp32 = 1 / (rms(x_m) + eps): rows < M_main from the dense layer's partial sums `ss`
+        [strips, ld], the others from x itself (evo_rms_finalize_f32)."""
+        M, D = x.shape
+        rstd = torch.empty((M + 255) // 256 * 256, dtype=torch.float32, device=x.device)
+        with self._t("rms_finalize"):
+            _check(self.lib.evo_rms_finalize_f32(_ptr(ss), 0 if ss is None else ss.shape[0], 0 if ss is None else ss.shape[1], x.data_ptr(),
+                                                 M_main, M, D, float(eps), rstd.data_ptr(), _stream()), "evo_rms_finalize_f32")
+        return rstd
+
+    def linear_residual_stats_(self, res: torch.Tensor, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], eps: float):
+        """res += x @ w^T (+ bias) in place, as linear_residual_, and the RMSNorm factor of every updated row: rstd [.] fp32.  The
+        main rows' sums of squares come out of the dense layer's epilogue."""
+        M, N = res.shape
+        K = w.shape[1]
+        Mm = self._nf_main_rows(M)
+        ss = torch.empty(N // 128, (Mm + 255) // 256 * 256, dtype=torch.float32, device=res.device)
+        with self._t("gemm_mfma"):
+            _check(self.lib.evo_linear_mfma_nf_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), res.data_ptr(), res.data_ptr(), None, ss.data_ptr(),
+                                                    ss.shape[1], Mm, N, K, _stream()), "evo_linear_mfma_nf_bf16")
+        if M > Mm:
+            self._linear_small_m(x[Mm:], w, bias, res[Mm:])
+        return self.rms_finalize(ss, res, Mm, eps)
+
+    def linear_residual_yblk_stats_(self, res: torch.Tensor, y_blk: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], eps: float):
+        """linear_residual_yblk_ + the RMSNorm factor of every updated row (see linear_residual_stats_)."""
+        M, N = res.shape
+        K = w.shape[1]
+        Mf = M // 256 * 256
+        ss = torch.empty(N // 128, Mf, dtype=torch.float32, device=res.device)
+        with self._t("gemm_mfma"):
+            _check(self.lib.evo_linear_xblk_mfma_nf_bf16(y_blk.data_ptr(), w.data_ptr(), _ptr(bias), res.data_ptr(), res.data_ptr(), ss.data_ptr(),
+                                                         Mf, Mf, N, K, _stream()), "evo_linear_xblk_mfma_nf_bf16")
+        if M > Mf:
+            r = M - Mf
+            tail = y_blk[Mf // self.YBLK:].permute(0, 2, 1, 3).reshape(-1, K)[:r].contiguous()
+            self.linear_residual_(res[Mf:], tail, w, bias=bias)
+        return self.rms_finalize(ss, res, Mf, eps)
+
+    def linear_rs(self, x: torch.Tensor, rstd: torch.Tensor, w_folded: torch.Tensor, b: Optional[torch.Tensor], w: torch.Tensor,
+                  scale: torch.Tensor, eps: float) -> torch.Tensor:
+        """linear(rmsnorm(x) * scale, w, b) with the norm as a row factor in the dense layer's epilogue: x is the raw stream, rstd its
+        rows' factors, w_folded = fold_norm_scale(w, scale); the sliver rows take the norm-folding weight-streaming launch on w itself."""
+        M, K = x.shape
+        N = w.shape[0]
+        Mm = self._nf_main_rows(M)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        with self._t("gemm_mfma"):
+            _check(self.lib.evo_linear_mfma_nf_bf16(x.data_ptr(), w_folded.data_ptr(), _ptr(b), None, y.data_ptr(), rstd.data_ptr(), None, 0,
+                                                    Mm, N, K, _stream()), "evo_linear_mfma_nf_bf16")
+        if M > Mm:
+            y[Mm:] = self.norm_linear(x[Mm:], scale, eps, w, b)
+        return y
+
+    def mlp_gate_rs(self, x: torch.Tensor, rstd: torch.Tensor, w12g_folded: torch.Tensor, w12: torch.Tensor, scale: torch.Tensor,
+                    eps: float) -> torch.Tensor:
+        """mlp_gate(rmsnorm(x) * scale, w12) with the norm as a row factor in the gated dense layer's epilogue (see linear_rs);
+        w12g_folded = pack_gate_weights(fold_norm_scale(w12, scale))."""
+        M, K = x.shape
+        I = w12.shape[0] // 2
+        Mm = self._nf_main_rows(M)
+        a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+        with self._t("gemm_gate"):
+            _check(self.lib.evo_mlp_gate_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w12g_folded.data_ptr(), a.data_ptr(), Mm, I, K, _stream()),
+                   "evo_mlp_gate_mfma_nf_bf16")
+        if M > Mm:
+            a[Mm:] = self.mlp_gate(x[Mm:], w12, scale, eps)
+        return a
+
+    def linear_t_rs(self, x: torch.Tensor, rstd: torch.Tensor, w_folded: torch.Tensor, b: Optional[torch.Tensor], w: torch.Tensor,
+                    scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
+        """linear_t(rmsnorm_rows(x), w, b) for the TAIL form of z^T (zt_layout: r > 0) without the normalised copy: the swapped-operand
+        dense layer reads the raw stream x [B T, K] (position b Tm + t = row b T + t) and scales by rstd in its epilogue; the B r tail
+        tokens take the norm-folding weight-streaming launch on w itself."""
+        Tm, Tp, Mp, r = self.zt_layout(B, T)
+        assert r > 0 and Tp == Tm and Mp == B * Tm and Tm % 256 == 0
+        K = x.shape[1]
+        N = w.shape[0]
+        zt = torch.empty(Mp // 256 + 1, N, 256, dtype=torch.bfloat16, device=x.device)
+        with self._t("gemm_zt"):
+            _check(self.lib.evo_linear_t_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w_folded.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K,
+                                                      B * T, Tm, r, _stream()), "evo_linear_t_mfma_nf_bf16")
+        zt[-1].zero_()
+        x_tail = x.view(B, T, K)[:, Tm:].reshape(B * r, K).contiguous()                           # (a copy of B r <= 16 rows)
+        z_tail = self.norm_linear(x_tail, scale, eps, w, b)                             # [B r, N]
+        zt[-1].view(N, 32, 8)[:, :B, :r] = z_tail.view(B, r, N).permute(2, 0, 1)        # position Mp + 8 b + j
+        return zt
 
     # The same operator in two stages, for sequence parallelism: stage 1 (launches 1+2) yields the shard's end
     # state from a ZERO carry-in; after the ranks exchange those, stage 2 (carry-add + launch 3) finishes.

@@ -203,6 +203,11 @@ class StripedHyena(nn.Module):
             # csrc/gemm.hip) are a copy (180 MB per layer at D = 4096: 5.8 GB for 32 layers; the decode kernels stream `w12` as it is):
             # built on the first prefill-sized call (_gate_pack), so that decode-only use never pays for it
             blk.mlp._w12g = None
+            blk.mlp._w12g_f = None                            # ... and its norm-folded form (_folded), like the projections' below
+            if isinstance(blk, _HyenaBlock):
+                blk._wp_f = None
+            else:
+                blk.inner_mha_cls._wqkv_f = None
             blk.mlp._w12g_ok = (2 * ipad) % 256 == 0 and ipad % 32 == 0 and D_ % 64 == 0 and D_ >= 128
             if isinstance(blk, _HyenaBlock):
                 f = blk.filter
@@ -226,8 +231,16 @@ class StripedHyena(nn.Module):
             if not self._packed:
                 self._pack()
             if prefill:
+                nf = getattr(self.ops, "fuse_norm", False) and hasattr(self.ops, "fold_norm_scale") and self.blocks[0].mlp._w12g_ok
                 for blk in self.blocks:
-                    self._gate_pack(blk, 1 << 20)
+                    if nf:                                   # the norm-folded copies the prefill launches read (see _nf_ok)
+                        self._folded(blk.mlp, "_w12g_f", blk.mlp._w12, blk.post_norm.scale, gate=True)
+                        if isinstance(blk, _HyenaBlock):
+                            self._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
+                        else:
+                            self._folded(blk.inner_mha_cls, "_wqkv_f", blk.inner_mha_cls.Wqkv.weight, blk.pre_norm.scale)
+                    else:
+                        self._gate_pack(blk, 1 << 20)
                     if isinstance(blk, _HyenaBlock) and hasattr(self.ops, "hyena_ct"):
                         self._mfma_table(blk)
         return self
@@ -307,6 +320,46 @@ class StripedHyena(nn.Module):
         self.ops.linear_residual_(x2d, y, w, mfma=mfma, bias=bias)
         return None
 
+    # ---- RMSNorm folded into the dense layers around it (round 5; csrc/gemm.hip NF, include/evo_mi355x.h) ---------------------------
+    # The dense layer that writes the residual stream (mixer output projection, l3) also emits every row's 1 / (rms + eps) -- `rs` below,
+    # handed from block to block --, and the layer that consumes the norm (Hyena projections, Wqkv, l1 | l2) reads the stream itself and
+    # applies rs in its epilogue, with the norm's scale vector folded into a copy of its weight.  What remains of the 65 RMSNorm
+    # passes of a forward: block 0's pre-norm (the embedding has no dense layer in front of it) and the final norm.
+    def _nf_ok(self, M: int, mask) -> bool:
+        ops = self.ops
+        D = self.hidden_size
+        if mask is not None or not getattr(ops, "fuse_norm", False) or not hasattr(ops, "nf_shape_ok"):
+            return False
+        ipad = self.blocks[0].mlp._w12.shape[0] // 2
+        return (ops.nf_shape_ok(M, D, D) and ops.nf_shape_ok(M, 3 * D, D) and ops.nf_shape_ok(M, 2 * ipad, D) and ops.nf_shape_ok(M, D, ipad)
+                and getattr(self.blocks[0].mlp, "_w12g_ok", False) and getattr(ops, "mlp_gate_fused", False))
+
+    def _folded(self, owner, name: str, w: torch.Tensor, g: torch.Tensor, gate: bool = False) -> torch.Tensor:
+        """bf16(W diag(g)) of a norm-consuming layer (for l1 | l2: in the gated launch's row order), built on first use / by prepare()."""
+        hit = getattr(owner, name, None)
+        if hit is None or hit.device != w.device:
+            with torch.inference_mode(False), torch.no_grad():
+                hit = self.ops.fold_norm_scale(w.data, g.data)
+                if gate:
+                    hit = self.ops.pack_gate_weights(hit)
+            setattr(owner, name, hit)
+        return hit
+
+    def _mixer_out_rs_(self, blk, x2d, y, w, bias):
+        """_mixer_out_ + the post-mixer norm's row factors."""
+        if y.dim() == 4:
+            return self.ops.linear_residual_yblk_stats_(x2d, y, w, bias, self.eps)
+        return self.ops.linear_residual_stats_(x2d, y, w, bias, self.eps)
+
+    def _mlp_residual_rs_(self, blk, x2d, rs_post):
+        """The block's MLP on the raw stream (post-norm as a row factor in the gated launch), residual added in place; returns the NEXT
+        pre-norm's row factors (l3's epilogue statistic)."""
+        ops = self.ops
+        mlp = blk.mlp
+        w12g_f = self._folded(mlp, "_w12g_f", mlp._w12, blk.post_norm.scale, gate=True)
+        a = ops.mlp_gate_rs(x2d, rs_post, w12g_f, mlp._w12, blk.post_norm.scale, self.eps)
+        return ops.linear_residual_stats_(x2d, a, mlp._w3, None, self.eps)
+
     def _gate_pack(self, blk, M: int):
         """The regrouped l1 | l2 weight of the one-launch gated MLP, built the first time a prefill-sized batch needs it."""
         mlp = blk.mlp
@@ -358,7 +411,7 @@ class StripedHyena(nn.Module):
         return (getattr(ops, "hyena_ct_flag", False) and hasattr(ops, "hyena_ct") and x2d.is_cuda and w.dtype == torch.bfloat16
                 and w.is_contiguous() and ops.zt_shape_ok(B, T, w.shape[0], w.shape[1]))
 
-    def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams], mask=None):
+    def _hyena_block(self, i, blk, x2d, B, T, cache: Optional[RecurrentInferenceParams], mask=None, rs=None):
         """`mask` = (flat [B*T,1] bf16, [B,T] uint8) of upstream's padding_mask, or None: the projections output, the FIR
         output and the mixer output + residual are multiplied by it, as upstream's ParallelGatedConvBlock /
         engine.parallel_fir do [UPSTREAM-RECALLED; evo never passes one, SURVEY 8b]."""
@@ -381,8 +434,15 @@ class StripedHyena(nn.Module):
             # registers (no window in LDS); y BLOCKED: the operator stores whole cache lines and the output projection's dense layer
             # gathers them -- no row-major y exists on this path.
             table = self._mfma_table(blk)
-            xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
-            zt = ops.linear_t(xp, blk.projections.weight.data, None if blk.projections.bias is None else blk.projections.bias.data, B, T)
+            nf = self._nf_ok(B * T, mask)
+            pb = None if blk.projections.bias is None else blk.projections.bias.data
+            if nf and rs is not None and ops.zt_layout(B, T)[3] > 0:
+                # pre-norm folded: the projection reads the stream itself (tail form of z^T: no padded copy is needed either)
+                wp_f = self._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
+                zt = ops.linear_t_rs(x2d, rs, wp_f, pb, blk.projections.weight.data, blk.pre_norm.scale, self.eps, B, T)
+            else:
+                xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
+                zt = ops.linear_t(xp, blk.projections.weight.data, pb, B, T)
             yb = ops.yblk_empty(B * T, D, zt.device)
             if cache is None:
                 y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)
@@ -395,8 +455,10 @@ class StripedHyena(nn.Module):
                                         want_state=True, poles=f._poles, y_blk=yb)
                 cache.fir_state_dict[i] = ops.zt_rows(zt, B, T, T - K1, K1).transpose(1, 2).contiguous()   # [B, 3D, 2]
                 cache.state_dict[i] = state
+            if nf:
+                return self._mlp_residual_rs_(blk, x2d, self._mixer_out_rs_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias))
             self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias), None)
-            return
+            return None
         else:
             z = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias)   # [B*T, 3D]
             if mask is not None:
@@ -420,6 +482,7 @@ class StripedHyena(nn.Module):
                 cache.state_dict[i] = state
         self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias),
                             None if mask is None else mask[0])
+        return None
 
     def _kv_buffer(self, cache: InferenceParams, i: int, B: int, need: int, like: torch.Tensor):
         H, hd = self.num_heads, self.head_dim
@@ -436,13 +499,18 @@ class StripedHyena(nn.Module):
             cache.key_value_memory_dict[i] = kv = new
         return kv
 
-    def _attn_block(self, i, blk, x2d, B, T, cache: Optional[InferenceParams], mask=None):
+    def _attn_block(self, i, blk, x2d, B, T, cache: Optional[InferenceParams], mask=None, rs=None):
         ops = self.ops
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         mha = blk.inner_mha_cls
         if mask is not None:                      # upstream AttentionBlock: u * padding_mask before and after the mixer
             x2d.mul_(mask[0])
-        qkv = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
+        nf = T > 1 and self._nf_ok(B * T, mask)
+        if nf and rs is not None:
+            wqkv_f = self._folded(mha, "_wqkv_f", mha.Wqkv.weight, blk.pre_norm.scale)
+            qkv = ops.linear_rs(x2d, rs, wqkv_f, mha.Wqkv.bias, mha.Wqkv.weight, blk.pre_norm.scale, self.eps).view(B, T, 3, H, hd)
+        else:
+            qkv = ops.norm_linear(x2d, blk.pre_norm.scale, self.eps, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, T, 3, H, hd)
         off = int(cache.seqlen_offset) if cache is not None else 0
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]
@@ -473,8 +541,11 @@ class StripedHyena(nn.Module):
                 a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
             else:
                 a = ops.attention(q, k, v, off).view(B * T, D)
+        if nf:
+            return self._mlp_residual_rs_(blk, x2d, self._mixer_out_rs_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias))
         self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias, mfma=True),
                             None if mask is None else mask[0])
+        return None
 
     # ------------------------------------------------------------------ forward
     def hidden_states(self, x: torch.Tensor, inference_params_dict=None, padding_mask=None) -> torch.Tensor:
@@ -497,16 +568,18 @@ class StripedHyena(nn.Module):
         dyn = T == 1 and mha_c is not None and getattr(mha_c, "pos_tensor", None) is not None
         if dyn and not hasattr(ops, "rope_append_decode"):   # (fallback path) one rotary table per decode step for all layers
             mha_c._rot_dyn = self._rotary_dyn(mha_c.pos_tensor)
+        rs = None
         taps = getattr(self, "block_taps", None)     # debugging / parity hook: residual stream entering every block
         tap_idxs = getattr(self, "block_tap_idxs", None)   # ... or only the listed ones (index num_layers = the final stream)
         try:
             for i, blk in enumerate(self.blocks):
                 if taps is not None and (tap_idxs is None or i in tap_idxs):
                     taps.append(h.clone())
+                # rs: 1 / (rms + eps) of every row of h, from the epilogue of the dense layer that wrote it (None: the block norms h itself)
                 if isinstance(blk, _AttentionBlock):
-                    self._attn_block(i, blk, h, B, T, mha_c, mask)
+                    rs = self._attn_block(i, blk, h, B, T, mha_c, mask, rs)
                 else:
-                    self._hyena_block(i, blk, h, B, T, hy_c, mask)
+                    rs = self._hyena_block(i, blk, h, B, T, hy_c, mask, rs)
             if taps is not None and (tap_idxs is None or self.num_layers in tap_idxs):
                 taps.append(h.clone())
         finally:

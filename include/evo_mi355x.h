@@ -38,8 +38,11 @@ extern "C" {
  *   8: evo_attn_fwd_causal_bf16 gained `vt_ws` (workspace for V^T: the round-5 prefill kernel of csrc/attn_w64.hip reads its V
  *      fragments from a transposed copy); evo_hyena_mfma, evo_hyena_mfma_state, evo_hyena_mfma_zg, evo_hyena_cs_zg and
  *      evo_linear_zg_mfma_bf16 REMOVED (the earlier forms of the single-pass Hyena operator and the group-major projection that
- *      fed them: every caller is on evo_hyena_ct). */
-#define EVO_ABI_VERSION 8
+ *      fed them: every caller is on evo_hyena_ct).
+ *   9: the RMSNorm passes folded into the dense layers around them: evo_linear_mfma_nf_bf16, evo_linear_xblk_mfma_nf_bf16,
+ *      evo_mlp_gate_mfma_nf_bf16, evo_linear_t_mfma_nf_bf16 (the same launches with a per-row factor in / the rows' sums of squares
+ *      out) and evo_rms_finalize_f32 added; no signature changed. */
+#define EVO_ABI_VERSION 9
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -240,6 +243,33 @@ int evo_linear_mfma_bf16(const void* x, const void* w, const void* bias, const v
  * blocks of 64: rows 32 q .. 32 q + 31 of W1 followed by the same rows of W2 (q = 0 .. I / 32 - 1).
  * (2 I) % 256 == 0, K % 64 == 0, K >= 128, any M >= 1.  Returns -1 for an unsupported shape. */
 int evo_mlp_gate_mfma_bf16(const void* x, const void* w12g, void* a, int64_t M, int64_t I, int64_t K, void* stream);
+
+/* ---- RMSNorm folded into the dense layers around it (prefill-sized batches) ---------------------------------------------
+ * replaces the RMSNorm pass between two dense layers          [REF stripedhyena/model.py: pre_norm / post_norm of every block;
+ *                                                              stripedhyena/layers.py RMSNorm.forward]
+ * The reference writes n = bf16(g * x / (rms(x) + eps)) and multiplies it by the next layer's weight W.  Here the dense layer that
+ * WRITES the residual stream x also emits each row's sum of squares, and the layer that consumes the norm reads x itself:
+ *     W n  =  r_m * ((W diag(g)) x_m),   r_m = 1 / (rms(x_m) + eps)
+ * with W diag(g) a bf16 copy of the weight the caller folds once (one rounding of the weight where the reference rounds the
+ * activation) and r_m applied to the fp32 accumulators before bias / gate / the one output rounding.
+ *   sumsq  [N / 128][ss_ld] fp32 out: per 128-column strip of the stored rows, the sum of squares of the ROUNDED values of row m
+ *          (ss_ld >= M rounded up to 256; rows beyond M are scratch).  Needs `residual` (the launches that write the stream).
+ *   row_scale [M rounded up to 256] fp32 in: r_m.  Launches without a residual.
+ *   evo_rms_finalize_f32: rstd[m] = 1 / (sqrt(sum over strips) / sqrt(D) + eps) for m < M_main (strip order: bit-reproducible), and
+ *          computed from the rows of x [M, D] bf16 themselves for M_main <= m < M (the rows a weight-streaming launch wrote).
+ *   evo_linear_t_mfma_nf_bf16: additionally reads its token rows from the stream in (batch row, token) order: position p = b Tm + t
+ *          of z^T (Mp = B Tm, Tm % 256 == 0) is row p + b row_skip of x [x_rows, K] -- the tail form of z^T; row_scale has x_rows
+ *          entries.  row_scale == NULL: the plain launch (x_rows = Tm = Mp, row_skip = 0).
+ * Shape contracts as the plain entries'; K >= 128 and operands below 4 GiB (the persistent kernel). */
+int evo_linear_mfma_nf_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                            const float* row_scale, float* sumsq, int64_t ss_ld, int64_t M, int64_t N, int64_t K, void* stream);
+int evo_linear_xblk_mfma_nf_bf16(const void* x_blk, const void* w, const void* bias, const void* residual, void* y,
+                                 float* sumsq, int64_t ss_ld, int64_t M, int64_t N, int64_t K, void* stream);
+int evo_mlp_gate_mfma_nf_bf16(const void* x, const float* row_scale, const void* w12g, void* a, int64_t M, int64_t I, int64_t K, void* stream);
+int evo_linear_t_mfma_nf_bf16(const void* x, const float* row_scale, const void* w, const void* bias, void* zt, int64_t Mp, int64_t N,
+                              int64_t K, int64_t x_rows, int64_t Tm, int64_t row_skip, void* stream);
+int evo_rms_finalize_f32(const float* sumsq, int64_t n_strips, int64_t ss_ld, const void* x, int64_t M_main, int64_t M, int64_t D,
+                         float eps, float* rstd, void* stream);
 
 /* ---- Hyena mixer input of one decode step, fused ---------------------------------------------------------------
  * replaces pre-norm + projections GEMV + step_fir + step_iir of the single-token forward   [REF evo/generation.py:111-114,138-155]

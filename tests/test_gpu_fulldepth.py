@@ -174,7 +174,7 @@ def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
     assert err <= floor                                       # never further from fp32 than eager bf16 is
 
 
-@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "attention_round4", "modal_hyena"])
+@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "attention_round4", "modal_hyena", "norm_unfused"])
 def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     """(b) BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
     oracle run on that prefix alone (the model is causal) -- end to end, and block by block with the engine's own
@@ -184,17 +184,19 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     GELU * gate in the epilogue; attention on attn_fwd_w64_kernel -- launch counts asserted: zero library GEMMs), and the in-process
     A/B routings bench.py times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt),
     `unfused` (dense layer + gate kernel), `attention_round4` (ops.attn_w64 = False: the 8-wave attention kernel of rounds 2-4) and
-    `modal_hyena` (ops.hyena_mfma = False: the three-launch modal Hyena kernels on token-major z)."""
+    `modal_hyena` (ops.hyena_mfma = False: the three-launch modal Hyena kernels on token-major z), `norm_unfused` (ops.fuse_norm = False:
+    the 65 separate RMSNorm passes of rounds 1-4 instead of the norm folded into the dense layers' epilogues)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P, row = 2049, 3
     ids = acgt_ids(8, 8192)
     m = full["m8"]
     ops = m.ops
-    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma
+    was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma, ops.fuse_norm
     ops.all_gemm_mfma = gemm != "library_l3"
     ops.mlp_gate_fused = gemm != "unfused"
     ops.attn_w64 = gemm != "attention_round4"
     ops.hyena_mfma = gemm != "modal_hyena"
+    ops.fuse_norm = gemm != "norm_unfused"
     if ops.timer is None:
         from evo_amd.ops import KernelTimer
         ops.timer = KernelTimer()
@@ -207,7 +209,7 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
         launches = {k_: n for k_, (n, _) in ops.timer.summary().items()}
     finally:
         m.block_taps = None
-        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma = was
+        ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma, ops.fuse_norm = was
         ops.timer = None
     # the routing under test really ran (here `model(ids)` materialises logits through ops.linear: one more dense layer than a
     # scoring step, whose unembedding is fused into the tail kernel)
@@ -217,6 +219,15 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     else:
         assert launches.get("gemm_zt", 0) == 29 and launches.get("hyena_mfma", 0) == 29 and launches.get("hyena_apply", 0) == 0
     assert launches.get("attn_fwd", 0) == 3
+    # the RMSNorm passes: folded into the dense layers on the default routing (what is left: block 0's pre-norm and the final norm);
+    # the folding needs the hand-written dense layer everywhere and the gated launch, the modal Hyena path norms for itself
+    n_norm = launches.get("rmsnorm", 0)
+    if gemm in ("default", "attention_round4"):
+        assert n_norm == 2 and launches.get("rms_finalize", 0) == 64, launches
+    elif gemm == "modal_hyena":                            # (the modal Hyena path norms for itself; only the attention blocks' MLPs fold)
+        assert n_norm == 62 and launches.get("rms_finalize", 0) == 6, launches
+    else:
+        assert n_norm == 65 and launches.get("rms_finalize", 0) == 0, launches
     if gemm == "library_l3":
         assert launches.get("gemm", 0) >= 32 and launches.get("gemm_gate", 0) == 32
     elif gemm == "unfused":

@@ -227,3 +227,163 @@ def test_output_projection_on_the_blocked_hyena_output_is_the_row_major_dense_la
     ref = (y.double() @ w.double().t() + res.double()) + (0 if bias is None else bias.double())
     err = (got.double() - ref).abs()
     assert (err <= ref.abs() * 2.0 ** -8 + 2e-3 * float(ref.abs().max())).all()
+
+
+# ---- RMSNorm folded into the dense layers around it (gemmr_bf16_kernel NF; include/evo_mi355x.h) ----------------------------------
+def _pow2_rows(M, g):
+    """A per-row factor that is a power of two (2^-3 .. 2^3): scaling by it commutes with every rounding, so a launch with this row
+    factor must equal the plain launch's result times the factor BIT FOR BIT (no bias) -- an exact check of which row gets which factor."""
+    e = torch.randint(-3, 4, (M,), device="cuda", generator=g)
+    return torch.ldexp(torch.ones(M, device="cuda"), e).float()
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(512, 256, 128, False), (1026, 768, 256, True), (2049, 4096, 4096, True), (4104, 512, 1024, False)])
+def test_stream_writing_dense_layer_emits_the_rows_rms_factor(M, N, K, bias):
+    """evo_linear_mfma_nf_bf16 (sumsq) + evo_rms_finalize_f32 through ops.linear_residual_stats_: the residual update equals the plain
+    launch bit for bit, and rstd[m] = 1 / (rms(updated row m) + eps) for EVERY row -- main rows from the epilogue's partial sums,
+    the sliver rows (M % 256 <= 16: the weight-streaming launch) from the rows themselves."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+    res = (torch.randn(M, N, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    want = ops.linear_residual_(res.clone(), x, w, mfma=True, bias=b)
+    got = res.clone()
+    eps = 1e-6
+    rstd = ops.linear_residual_stats_(got, x, w, b, eps)
+    assert torch.equal(got, want)
+    ref = 1.0 / (got.double().pow(2).sum(-1).sqrt() * N ** -0.5 + eps)
+    rel = ((rstd[:M].double() - ref).abs() / ref).max().item()
+    assert rstd.dtype == torch.float32 and rstd.numel() >= M and rel < 2e-6, rel
+    again = res.clone()
+    assert torch.equal(ops.linear_residual_stats_(again, x, w, b, eps)[:M], rstd[:M])      # fixed summation order: reproducible
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1032, 512, 256), (4104, 4096, 4096)])
+def test_blocked_input_dense_layer_emits_the_rows_rms_factor(M, N, K):
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    y = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    yb = ops.yblk_empty(M, K, "cuda")
+    yb.zero_()
+    nrb = yb.shape[0]
+    ypad = torch.zeros(nrb * 128, K, dtype=torch.bfloat16, device="cuda")
+    ypad[:M] = y
+    yb.copy_(ypad.view(nrb, 128, K // 16, 16).permute(0, 2, 1, 3))
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    want = ops.linear_residual_yblk_(res.clone(), yb, w, bias=b)
+    got = res.clone()
+    rstd = ops.linear_residual_yblk_stats_(got, yb, w, b, 1e-6)
+    assert torch.equal(got, want)
+    ref = 1.0 / (got.double().pow(2).sum(-1).sqrt() * N ** -0.5 + 1e-6)
+    assert ((rstd[:M].double() - ref).abs() / ref).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1026, 768, 256), (2049, 12288, 4096)])
+def test_row_factor_in_the_dense_layers_epilogue(M, N, K):
+    """evo_linear_mfma_nf_bf16 (row_scale) through ops.linear_rs: (a) with power-of-two factors and no bias the result is the plain
+    launch's, scaled -- bit for bit, every row; (b) with the real factors, the folded weight and a bias: within one bf16 rounding of
+    r_m (W diag(g)) x_m + b in fp64, and as close to the fp64 norm -> dense layer as the two-pass form (rmsnorm, then the plain launch)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    scale = (1 + 0.1 * torch.randn(K, device="cuda", generator=g)).to(torch.bfloat16)
+    eps = 1e-6
+    Mm = ops._nf_main_rows(M)
+    p2 = torch.ones((M + 255) // 256 * 256, device="cuda")
+    p2[:M] = _pow2_rows(M, g)
+    ones = torch.ones(K, dtype=torch.bfloat16, device="cuda")
+    plain = ops.linear_mfma(x[:Mm].contiguous(), w, None)
+    got = ops.linear_rs(x, p2, w, None, w, ones, eps)
+    assert torch.equal(got[:Mm].float(), plain.float() * p2[:Mm, None])
+    rstd = ops.rms_finalize(None, x, 0, eps)
+    wf = ops.fold_norm_scale(w, scale)
+    got = ops.linear_rs(x, rstd, wf, b, w, scale, eps)
+    exact = rstd[:M, None].double() * (x.double() @ wf.double().t()) + b.double()
+    err = (got.double() - exact).abs()
+    assert bool((err[:Mm] <= exact[:Mm].abs() * 2.0 ** -8 + 1e-3).all()), err[:Mm].max().item()
+    xd = x.double()
+    truth = ((xd / (xd.pow(2).sum(-1, keepdim=True).sqrt() * K ** -0.5 + eps)) * scale.double()) @ w.double().t() + b.double()
+    two_pass = ops.linear(ops.rmsnorm(x, None, scale, eps), w, b, mfma=True)
+    e_f, e_t = (got.double() - truth).norm() / truth.norm(), (two_pass.double() - truth).norm() / truth.norm()
+    print(f"[norm folded {M}x{N}x{K}] rel-L2 vs fp64 norm -> dense: folded {e_f:.3e}, two-pass {e_t:.3e}")
+    assert e_f <= 1.15 * e_t + 1e-5
+    err_t = (got.double() - truth).abs()
+    assert bool((err_t <= truth.abs() * 2.0 ** -7 + 2e-2).all())                      # (sliver rows included: the norm-folding weight-streaming launch)
+
+
+@pytest.mark.parametrize("M,I,K", [(512, 128, 128), (1026, 256, 256), (2049, 11008, 4096)])
+def test_row_factor_in_the_gated_launch(M, I, K):
+    """evo_mlp_gate_mfma_nf_bf16 through ops.mlp_gate_rs: unit factors == the plain gated launch bit for bit; real factors + folded
+    weight vs the two-pass form (rmsnorm, gated launch) against fp64."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + I + K)
+    x = (torch.randn(M, K, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    w12 = (torch.randn(2 * I, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    scale = (1 + 0.1 * torch.randn(K, device="cuda", generator=g)).to(torch.bfloat16)
+    eps = 1e-6
+    Mm = ops._nf_main_rows(M)
+    w12g = ops.pack_gate_weights(w12)
+    one = torch.ones((M + 255) // 256 * 256, device="cuda")
+    ones = torch.ones(K, dtype=torch.bfloat16, device="cuda")
+    plain = ops.mlp_gate(x[:Mm].contiguous(), w12, w12g=w12g)
+    assert torch.equal(ops.mlp_gate_rs(x, one, w12g, w12, ones, eps)[:Mm], plain)
+    rstd = ops.rms_finalize(None, x, 0, eps)
+    got = ops.mlp_gate_rs(x, rstd, ops.pack_gate_weights(ops.fold_norm_scale(w12, scale)), w12, scale, eps)
+    xd = x.double()
+    n = (xd / (xd.pow(2).sum(-1, keepdim=True).sqrt() * K ** -0.5 + eps)) * scale.double()
+    z = n @ w12.double().t()
+    truth = torch.nn.functional.gelu(z[:, :I]) * z[:, I:]
+    two_pass = ops.mlp_gate(ops.rmsnorm(x, None, scale, eps), w12, w12g=w12g)
+    e_f, e_t = (got.double() - truth).norm() / truth.norm(), (two_pass.double() - truth).norm() / truth.norm()
+    print(f"[norm folded, gated {M}x{I}x{K}] rel-L2 vs fp64: folded {e_f:.3e}, two-pass {e_t:.3e}")
+    assert e_f <= 1.15 * e_t + 1e-5
+
+
+@pytest.mark.parametrize("B,T,N,K", [(2, 513, 768, 256), (3, 1025, 768, 128), (8, 8193, 12288, 4096)])
+def test_row_factor_and_stream_rows_in_the_transposed_projection(B, T, N, K):
+    """evo_linear_t_mfma_nf_bf16 through ops.linear_t_rs (tail form of z^T): the launch reads its token rows from the stream in
+    (batch row, token) order and scales by the token's factor.  (a) power-of-two factors, no bias: every position of z^T equals the
+    plain swapped launch on a hand-gathered copy of the rows, scaled, bit for bit (which row, which factor); the tail block too;
+    (b) real factors: against linear_t(rmsnorm_rows(x)) and fp64."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(B * T + N + K)
+    M = B * T
+    x = (torch.randn(M, K, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    scale = (1 + 0.1 * torch.randn(K, device="cuda", generator=g)).to(torch.bfloat16)
+    eps = 1e-6
+    Tm, Tp, Mp, r = ops.zt_layout(B, T)
+    assert r > 0 and Tp == Tm
+    p2 = torch.ones((M + 255) // 256 * 256, device="cuda")
+    p2[:M] = _pow2_rows(M, g)
+    ones = torch.ones(K, dtype=torch.bfloat16, device="cuda")
+    xm = x.view(B, T, K)[:, :Tm].reshape(Mp, K).contiguous()                          # the main rows, gathered by hand
+    plain = torch.empty(Mp // 256, N, 256, dtype=torch.bfloat16, device="cuda")
+    from evo_amd.ops import _check, _stream
+    _check(ops.lib.evo_linear_t_mfma_bf16(xm.data_ptr(), w.data_ptr(), None, plain.data_ptr(), Mp, N, K, _stream()), "evo_linear_t_mfma_bf16")
+    zt = ops.linear_t_rs(x, p2, w, None, w, ones, eps, B, T)
+    fac = p2[:M].view(B, T)[:, :Tm].reshape(Mp // 256, 1, 256)
+    assert torch.equal(zt[:-1].float(), plain.float() * fac)
+    rstd = ops.rms_finalize(None, x, 0, eps)
+    zt = ops.linear_t_rs(x, rstd, ops.fold_norm_scale(w, scale), b, w, scale, eps, B, T)
+    two_pass = ops.linear_t(ops.rmsnorm_rows(x, scale, eps, B, T), w, b, B, T)
+    xd = x.double()
+    truth = ((xd / (xd.pow(2).sum(-1, keepdim=True).sqrt() * K ** -0.5 + eps)) * scale.double()) @ w.double().t() + b.double()   # [M, N]
+    bb = torch.arange(B, device="cuda")[:, None].expand(B, T).reshape(-1)
+    tt = torch.arange(T, device="cuda")[None, :].expand(B, T).reshape(-1)
+    pos = ops.zt_positions(B, T, bb, tt)
+
+    def rows(z):                                                                       # z^T -> [M, N] in (batch row, token) order
+        return z.permute(0, 2, 1).reshape(-1, N)[pos].double()
+    e_f, e_t = (rows(zt) - truth).norm() / truth.norm(), (rows(two_pass) - truth).norm() / truth.norm()
+    print(f"[norm folded, z^T {B}x{T}x{N}x{K}] rel-L2 vs fp64: folded {e_f:.3e}, two-pass {e_t:.3e}")
+    assert e_f <= 1.15 * e_t + 1e-5
+    ta, tb = rows(zt)[tt >= Tm], rows(two_pass)[tt >= Tm]                              # tail tokens: the weight-streaming launches on the same rows
+    assert bool(((ta - tb).abs() <= tb.abs() * 2.0 ** -7 + 1e-2).all())
