@@ -609,7 +609,7 @@ class HipOps:
         r = M % 256
         Mm = M - r if 1 <= r <= 16 else M
         return (self.fuse_norm and self.all_gemm_mfma and M >= 512 and N % 256 == 0 and K % 64 == 0 and K >= 128
-                and Mm * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff and Mm * N * 2 < 0xffffffff)
+                and Mm * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff)      # (operands below 4 GiB: the kernel's 32-bit DMA offsets; outputs are addressed per tile)
 
     def _nf_main_rows(self, M: int) -> int:
         r = M % 256

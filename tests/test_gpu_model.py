@@ -135,6 +135,60 @@ def test_cached_prefill_through_both_forms_of_zt_then_decode(P):
     assert rel_l2(steps, full[:, P:]) < 2 * tol
 
 
+@pytest.mark.parametrize("B,P", [(2, 1025), (1, 2050), (4, 1280)])   # tail form r = 1 + sliver rows; r = 2; plain form of z^T (pre-norm unfolded there)
+def test_norm_folded_forward_and_cached_prefill_vs_oracle(B, P):
+    """RMSNorm folded into the dense layers (csrc/gemm.hip NF; evo_amd/sh/model.py _nf_ok) on a model small enough for the fp64 oracle:
+    D = 512 (the gated launch and every dense layer shape take the fold), prompts of >= 512 rows.  (a) the fold really runs (launch
+    counts), (b) folded and unfolded forwards against the fp64 oracle: the folded one is no further away, (c) the cached prompt pass on
+    the folded path, then decode steps, continue the parallel forward."""
+    from evo_amd.ops import HipOps, KernelTimer
+    cfg, sd, m = build(SMALL4)
+    ops = m.ops
+    n_new = 4
+    ids = acgt(B, P - 1 + n_new)
+    ref = R.RefStripedHyena(cfg, sd, "fp64")(ids)[0]
+    floor = rel_l2(R.RefStripedHyena(cfg, sd, "bf16")(ids)[0], ref)
+    tol = max(1.5 * floor, 4e-3)
+    tail = HipOps.zt_layout(B, P)[3] > 0
+    if not m._packed:
+        m._pack()
+    assert m._nf_ok(B * P, None)
+    was = ops.fuse_norm
+    try:
+        errs = {}
+        for fold in (True, False):
+            ops.fuse_norm = fold
+            ops.timer = KernelTimer()
+            got = m(ids[:, :P].to(DEV))[0]
+            torch.cuda.synchronize()
+            n = {k: v[0] for k, v in ops.timer.summary().items()}
+            ops.timer = None
+            errs[fold] = rel_l2(got, ref[:, :P])
+            if fold:      # 3 Hyena blocks + 1 attention block: every post-norm and every pre-norm but block 0's is folded (the Hyena pre-norms only in
+                # the tail form).  What is left in the tail-form cases beside block 0's pre-norm and the final norm: the <= 16 sliver / tail rows
+                # of the three folded pre-norms, normed by the small kernel in front of the weight-streaming launch (at D = 4096 that launch
+                # norms for itself: gemv_norm)
+                assert n.get("rms_finalize", 0) == 8 and n.get("rmsnorm", 0) == (5 if tail else 4), n
+            else:
+                assert n.get("rms_finalize", 0) == 0 and n.get("rmsnorm", 0) == 9, n
+        print(f"[norm folded B={B} P={P}] logits rel-L2 vs fp64: folded {errs[True]:.3e}, separate passes {errs[False]:.3e} (eager-bf16 oracle {floor:.3e})")
+        assert errs[True] < tol and errs[True] <= 1.1 * errs[False] + 1e-4
+        ops.fuse_norm = True
+        c = m.initialize_inference_params()
+        c["mha"].max_batch_size = c["hyena"].max_batch_size = B
+        l0, c = m(ids[:, :P].to(DEV), c)
+        assert rel_l2(l0, ref[:, :P]) < tol
+        steps = []
+        for t in range(P, P + n_new):
+            c["mha"].seqlen_offset = c["hyena"].seqlen_offset = t
+            lt, c = m(ids[:, t:t + 1].to(DEV), c)
+            steps.append(lt[:, 0].float().cpu())
+        assert rel_l2(torch.stack(steps, 1), ref[:, P:]) < tol
+    finally:
+        ops.fuse_norm = was
+        ops.timer = None
+
+
 def test_evo_api_scores_vs_oracle():
     import evo_amd
     from evo_amd.tokenizer import CharLevelTokenizer
