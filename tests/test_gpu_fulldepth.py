@@ -535,8 +535,21 @@ def test_score_rel_distribution_64_sequences(full):
     print(f"[score distribution] first 16 (the round-3 sample): engine mean {rel[:16].mean():.3e} max {rel[:16].max():.2e}; "
           f"eager-bf16 mean {rel_flo[:16].mean():.3e} max {rel_flo[:16].max():.2e}")
     print("[score distribution] engine:", " ".join(f"{x:.1e}" for x in rel.tolist()))
-    assert rel.mean().item() <= 1.25e-3 and rel.mean().item() <= rel_flo.mean().item()
-    assert rel.max().item() <= rel_flo.max().item()
+    # round 5: the same 64 sequences with every RMSNorm as its own pass (ops.fuse_norm = False: rounds 1-4's arithmetic) -- the two
+    # routings differ by WHERE one rounding per norm sits (tests/PARITY.md 11b); through 32 chaotic blocks that is another sample of the
+    # same distribution (the mean of 64 has a standard error of ~1e-4), printed beside the default so that the shift is on record
+    was = m.ops.fuse_norm
+    m.ops.fuse_norm = False
+    try:
+        got_u = torch.cat([m(ids[i:i + 16].to(DEV))[0].cpu() for i in range(0, 64, 16)])
+    finally:
+        m.ops.fuse_norm = was
+    rel_u = ((score_of(got_u, ids) - s_ref).abs() / s_ref.abs())
+    print(f"[score distribution] norms as separate passes (fuse_norm = False): engine score_rel mean {rel_u.mean():.3e} max {rel_u.max():.2e} "
+          f"median {rel_u.median():.2e}; logits rel-L2 folded {rel_l2(got, ref):.4e}, separate {rel_l2(got_u, ref):.4e}, eager-bf16 {rel_l2(flo, ref):.4e}")
+    for r_ in (rel, rel_u):
+        assert r_.mean().item() <= 1.25e-3 and r_.mean().item() <= rel_flo.mean().item()
+        assert r_.max().item() <= rel_flo.max().item()
 
 
 # ---- (f) the north-star tolerance on trained-like weights ------------------------------------------------------------------------

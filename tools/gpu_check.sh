@@ -40,3 +40,11 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/profg -o g -- python $R/tools/bench_generate.py --new 128 > $R/$O/prof_gen.log 2>&1
 cd $R && python tools/summarize_prof.py stats $O/profg > $O/decode_kernel_stats.txt && rm -rf $O/profg
 tail -1 $O/prof_gen.log; head -8 $O/decode_kernel_stats.txt
+# SQ counters of the two prefill attention kernels (separate --pmc passes, --kernel-trace only) and the N = 2 code path of bench.py as a
+# shared-GPU self-test (two ranks on this one GPU through the host-staged communicator: launch / barrier / max-over-ranks / sharded 131k)
+if [ "$1" != "tests" ]; then
+bash tools/attn_counters.sh 2 > /dev/null 2>&1; bash tools/attn_counters.sh 1 > /dev/null 2>&1
+cp gpurun_out/attn_sq/form2.txt $O/attn_sq_form2.txt; cp gpurun_out/attn_sq/form1.txt $O/attn_sq_form1.txt
+EVO_AMD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --skip-cpu --skip-gen > $O/bench_n2_selftest.json 2> $O/bench_n2_selftest.err; echo "n2 self-test rc=$?"
+fi
+
