@@ -608,7 +608,8 @@ class HipOps:
         """Shapes whose main rows the persistent dense layer takes with the norm folded in (sliver rows <= 16 or none)."""
         r = M % 256
         Mm = M - r if 1 <= r <= 16 else M
-        return (self.fuse_norm and self.all_gemm_mfma and M >= 512 and N % 256 == 0 and K % 64 == 0 and K >= 128
+        # (below 1,024 rows a forward is launch-bound -- four row tiles on 256 CUs -- and the fold would trade 63 small norm launches for 64 finalize launches)
+        return (self.fuse_norm and self.all_gemm_mfma and M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 128
                 and Mm * K * 2 < 0xffffffff and N * K * 2 < 0xffffffff)      # (operands below 4 GiB: the kernel's 32-bit DMA offsets; outputs are addressed per tile)
 
     def _nf_main_rows(self, M: int) -> int:
@@ -684,15 +685,30 @@ class HipOps:
             a[Mm:] = self.mlp_gate(x[Mm:], w12, scale, eps)
         return a
 
+    def zt_stream_rows_ok(self, B: int, T: int) -> bool:
+        """z^T layouts whose main area the swapped-operand projection can fill straight from the stream's rows (linear_t_rs): the tail
+        form (rows of Tm = T - r positions: position b Tm + t = row b T + t), and the plain form when it has no pad position at all
+        (T a multiple of 64 and B T a multiple of 256: position p = row p)."""
+        Tm, Tp, Mp, r = self.zt_layout(B, T)
+        if r > 0:
+            return Tp == Tm and Mp == B * Tm and Tm % 256 == 0
+        return Tp == T and Mp == B * T
+
     def linear_t_rs(self, x: torch.Tensor, rstd: torch.Tensor, w_folded: torch.Tensor, b: Optional[torch.Tensor], w: torch.Tensor,
                     scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
-        """linear_t(rmsnorm_rows(x), w, b) for the TAIL form of z^T (zt_layout: r > 0) without the normalised copy: the swapped-operand
-        dense layer reads the raw stream x [B T, K] (position b Tm + t = row b T + t) and scales by rstd in its epilogue; the B r tail
-        tokens take the norm-folding weight-streaming launch on w itself."""
+        """linear_t(rmsnorm_rows(x), w, b) without the normalised copy, for the layouts of zt_stream_rows_ok: the swapped-operand dense layer
+        reads the raw stream x [B T, K] and scales by rstd in its epilogue; in the tail form the B r tail tokens take the norm-folding
+        weight-streaming launch on w itself."""
         Tm, Tp, Mp, r = self.zt_layout(B, T)
-        assert r > 0 and Tp == Tm and Mp == B * Tm and Tm % 256 == 0
+        assert self.zt_stream_rows_ok(B, T)
         K = x.shape[1]
         N = w.shape[0]
+        if r == 0:                                    # plain form without a single pad position: z^T position p IS row p of the stream
+            zt = torch.empty(Mp // 256, N, 256, dtype=torch.bfloat16, device=x.device)
+            with self._t("gemm_zt"):
+                _check(self.lib.evo_linear_t_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w_folded.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K,
+                                                          Mp, Mp, 0, _stream()), "evo_linear_t_mfma_nf_bf16")
+            return zt
         zt = torch.empty(Mp // 256 + 1, N, 256, dtype=torch.bfloat16, device=x.device)
         with self._t("gemm_zt"):
             _check(self.lib.evo_linear_t_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w_folded.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K,

@@ -436,8 +436,8 @@ class StripedHyena(nn.Module):
             table = self._mfma_table(blk)
             nf = self._nf_ok(B * T, mask)
             pb = None if blk.projections.bias is None else blk.projections.bias.data
-            if nf and rs is not None and ops.zt_layout(B, T)[3] > 0:
-                # pre-norm folded: the projection reads the stream itself (tail form of z^T: no padded copy is needed either)
+            if nf and rs is not None and ops.zt_stream_rows_ok(B, T):
+                # pre-norm folded: the projection reads the stream itself (z^T layouts without pad positions inside the main area: no padded copy either)
                 wp_f = self._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
                 zt = ops.linear_t_rs(x2d, rs, wp_f, pb, blk.projections.weight.data, blk.pre_norm.scale, self.eps, B, T)
             else:

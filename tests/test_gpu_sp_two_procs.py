@@ -83,7 +83,7 @@ def test_two_ranks_one_gpu_host_staged(cfg_name, B, L, attn_mode):
     _, _, m = G.build(cfgd)
     ids = G.acgt(B, L)
     # like with like: the sequence-parallel ranks (evo_amd/sp.py) run every RMSNorm as its own pass; the unsharded forward would fold
-    # the norms of a >= 512-row batch into its dense layers (another, equally valid set of roundings: tests/PARITY.md rows 11a-c)
+    # the norms of a >= 1,024-row batch into its dense layers (another, equally valid set of roundings: tests/PARITY.md rows 11a-c)
     was = m.ops.fuse_norm
     m.ops.fuse_norm = False
     try:
