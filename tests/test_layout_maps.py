@@ -210,3 +210,39 @@ def test_attn_w64_key_order_vt_image_and_dma_plan():
             for L in range(64):
                 row = 8 * j + (L >> 3)
                 assert ((row >> 1) & 7) == ((4 * (wave & 1) + (L >> 4)) & 7)
+
+
+def test_norm_fold_host_maps_and_the_stream_row_remap_of_the_transposed_projection():
+    """Round 5 (csrc/gemm.hip NF): the host-side pieces of the RMSNorm folding, restated and checked without a GPU.
+    * HipOps.fold_norm_scale = bf16(W diag(g)) with an fp32 product; * which rows the persistent launch takes and which go to the
+    weight-streaming launches (_nf_main_rows); * which z^T layouts can be filled straight from the stream (zt_stream_rows_ok);
+    * the kernel's row remap of mode 3 (`src_row`: position tile origin n0 -> n0 + (n0 / 256 / tm_tiles) * row_skip) lands every
+    position of the main area on the stream row HipOps.zt_positions assigns it, and a 256-position tile never straddles two batch rows;
+    * the statistic's geometry: 16 lanes x 8 m tiles x 2 wave rows cover a tile's 256 rows once per 128-column strip."""
+    import torch
+    from evo_amd.ops import HipOps
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 32, generator=g).to(torch.bfloat16)
+    s = (1 + 0.1 * torch.randn(32, generator=g)).to(torch.bfloat16)
+    f = HipOps.fold_norm_scale(w, s)
+    assert f.dtype == torch.bfloat16 and f.is_contiguous() and torch.equal(f, (w.float() * s.float()[None, :]).to(torch.bfloat16))
+    assert torch.equal(HipOps.fold_norm_scale(w, torch.ones(32, dtype=torch.bfloat16)), w)          # g = 1: the weight itself
+    main = lambda M: HipOps._nf_main_rows(HipOps, M)
+    assert [main(M) for M in (65544, 131073, 8192, 2100, 2050, 272, 273)] == [65536, 131072, 8192, 2100, 2048, 256, 273]
+    ok = lambda B, T: HipOps.zt_stream_rows_ok(HipOps, B, T)
+    assert ok(8, 8193) and ok(1, 131073) and ok(2, 1026) and ok(1, 8192) and ok(4, 1280)
+    assert not ok(3, 700) and not ok(3, 5003) and not ok(1, 8210)                                     # padded rows: rmsnorm_rows writes the copy
+    for B, T in ((8, 8193), (2, 1026), (3, 1025), (1, 131073)):
+        Tm, Tp, Mp, r = HipOps.zt_layout(B, T)
+        assert r > 0 and Tm % 256 == 0 and Mp == B * Tm
+        tm_tiles = Tm // 256
+        bb = torch.arange(B)[:, None].expand(B, Tm).reshape(-1)
+        tt = torch.arange(Tm)[None, :].expand(B, Tm).reshape(-1)
+        pos = HipOps.zt_positions(B, T, bb, tt)                                                       # position of (b, t), t < Tm
+        n0 = pos // 256 * 256
+        src = n0 + (n0 // 256 // tm_tiles) * r + pos % 256                                            # the kernel's source row of that position
+        assert torch.equal(src, bb * T + tt)
+        assert torch.equal(n0 // Tm, (n0 + 255) // Tm)                                                # one batch row per tile
+        assert int(src.max()) < B * T
+    rows = sorted(wm * 128 + 16 * j + l15 for wm in range(2) for j in range(8) for l15 in range(16))
+    assert rows == list(range(256))
