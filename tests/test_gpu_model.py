@@ -138,7 +138,7 @@ def test_cached_prefill_through_both_forms_of_zt_then_decode(P):
 @pytest.mark.parametrize("B,P", [(2, 1025), (1, 2050), (4, 1280), (3, 700)])   # tail form r = 1 + sliver rows; r = 2; plain form of z^T without pad positions (folded too); plain form with padded rows (Hyena pre-norms unfolded)
 def test_norm_folded_forward_and_cached_prefill_vs_oracle(B, P):
     """RMSNorm folded into the dense layers (csrc/gemm.hip NF; evo_amd/sh/model.py _nf_ok) on a model small enough for the fp64 oracle:
-    D = 512 (the gated launch and every dense layer shape take the fold), prompts of >= 512 rows.  (a) the fold really runs (launch
+    D = 512 (the gated launch and every dense layer shape take the fold), prompts of >= 1,024 rows.  (a) the fold really runs (launch
     counts), (b) folded and unfolded forwards against the fp64 oracle: the folded one is no further away, (c) the cached prompt pass on
     the folded path, then decode steps, continue the parallel forward."""
     from evo_amd.ops import HipOps, KernelTimer
