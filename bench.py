@@ -157,6 +157,160 @@ def flops_per_token(T):
     return 32 * 402_784_256 + 2 * 4096 * 512 + 24_576 * T
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# `box`: what THIS box gives.  The driver's headline fell 5.6 % between rounds 4 and 5 on a box where an unchanged
+# kernel ran 9 % slower: a bench line needs the box's own rates beside it.  Measured in this process right before the headline:
+#   * hbm_copy_GBs        evo_probe_copy_f4 over 1 GiB (read + write counted: 2 GiB per pass), HIP events
+#   * mfma_probe_tflops   evo_probe_mfma_bf16: register-resident 16x16x32 bf16 MFMA stream, 256 x 4 waves, ~0.2 s (long enough for the
+#                         power management to settle the clock), pseudo-random operands
+#   * library_gemm_tflops torch.mm (hipBLASLt, fixed by the image) 8,192^3 bf16 on N(0, 1) operands: the dense-layer rate this box sustains
+#                         with code that is not ours
+#   * clocks / power      /sys/class/drm/card*/device/hwmon (power average + cap, sclk, mclk), sampled by a thread over the timed region
+# `value_per_calibrated_box` = value / (share_dense * library_gemm / REF_GEMM + (1 - share_dense) * hbm_copy / REF_COPY): the headline on a
+# box that gives exactly the reference rates (REF_GEMM 1,500 TFLOP/s = the middle of the 1.42-1.6 PFLOP/s hipBLASLt range of rounds 2-5,
+# REF_COPY 6,290 GB/s = MI355X_MICROARCH.md's float4 copy); share_dense = this run's dense-layer share of the step.
+REF_GEMM_TFLOPS = 1500.0
+REF_COPY_GBS = 6290.0
+
+
+def _gpu_sysfs_dir(index=0):
+    """The hwmon directory of HIP device `index`, matched by PCI address (a container sees every card of the host under /sys/class/drm
+    but only its own GPUs through HIP), or None."""
+    import glob
+    cache = _gpu_sysfs_dir.__dict__.setdefault("cache", {})
+    if index in cache:
+        return cache[index]
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = "%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+    except Exception:  # noqa: BLE001
+        pass
+    hit = None
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        dev = os.path.realpath(os.path.join(card, "device"))
+        hw = sorted(glob.glob(os.path.join(card, "device", "hwmon", "hwmon*")))
+        if not hw:
+            continue
+        if want is not None and os.path.basename(dev).lower() == want.lower():
+            hit = hw[0]
+            break
+    cache[index] = hit
+    return hit
+
+
+def _read_int(path):
+    try:
+        with open(path) as fh:
+            return int(fh.read().strip())
+    except (OSError, ValueError):
+        return None
+
+
+def gpu_telemetry(index=0):
+    """One reading: {power_W, power_cap_W, sclk_MHz, mclk_MHz, temp_C}; missing entries are None (sysfs layouts differ)."""
+    d = _gpu_sysfs_dir(index)
+    if d is None:
+        return {}
+    pw = _read_int(os.path.join(d, "power1_average"))
+    if pw is None:
+        pw = _read_int(os.path.join(d, "power1_input"))
+    cap = _read_int(os.path.join(d, "power1_cap"))
+    f1, f2 = _read_int(os.path.join(d, "freq1_input")), _read_int(os.path.join(d, "freq2_input"))
+    tp = _read_int(os.path.join(d, "temp1_input"))
+    return {"power_W": None if pw is None else pw / 1e6, "power_cap_W": None if cap is None else cap / 1e6,
+            "sclk_MHz": None if f1 is None else f1 / 1e6, "mclk_MHz": None if f2 is None else f2 / 1e6,
+            "temp_C": None if tp is None else tp / 1e3}
+
+
+class TelemetrySampler:
+    """Samples gpu_telemetry() every `period` s on a host thread while a timed region runs (the reads are sysfs files: no GPU work)."""
+
+    def __init__(self, index=0, period=0.05):
+        import threading
+        self.index, self.period, self.rows = index, period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            r = gpu_telemetry(self.index)
+            if r:
+                self.rows.append(r)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=2.0)
+
+    def summary(self):
+        out = {"samples": len(self.rows)}
+        for k in ("power_W", "sclk_MHz", "mclk_MHz", "temp_C"):
+            v = [r[k] for r in self.rows if r.get(k) is not None]
+            if v:
+                out[k + "_mean"] = sum(v) / len(v)
+                out[k + "_min"], out[k + "_max"] = min(v), max(v)
+        caps = [r["power_cap_W"] for r in self.rows if r.get("power_cap_W") is not None]
+        if caps:
+            out["power_cap_W"] = caps[0]
+        return out
+
+
+def box_probes(ops, device, local=0):
+    """The box's own rates, measured now (see the comment above).  Every probe: 2 warm-up launches, then HIP events around the timed ones."""
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+
+    def ev_ms(fn, reps):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 256)
+    dst = torch.empty_like(src)
+
+    def copy():
+        rc = ops.lib.evo_probe_copy_f4(src.data_ptr(), dst.data_ptr(), n, st)
+        assert rc == 0, rc
+    ms = ev_ms(copy, 20)
+    out["hbm_copy_GBs"] = 2.0 * n / (ms * 1e-3) / 1e9
+    out["hbm_copy_bytes"] = n
+    del src, dst
+    sink = torch.empty(256 * 256, dtype=torch.float32, device=device)
+    iters = 60000                                        # 256 x 4 waves x 60,000 x 16 MFMAs of 16,384 flop = 1.03e15 flop: ~0.5 s at 2 PFLOP/s
+
+    def mf():
+        rc = ops.lib.evo_probe_mfma_bf16(sink.data_ptr(), 256, iters, st)
+        assert rc == 0, rc
+    with TelemetrySampler(local) as tel:
+        ms = ev_ms(mf, 2)
+    out["mfma_probe_tflops"] = 256 * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12
+    out["mfma_probe_ms"] = ms
+    out["mfma_probe_telemetry"] = tel.summary()
+    g = torch.Generator(device=device).manual_seed(7)
+    a_ = torch.randn(8192, 8192, generator=g, device=device).bfloat16()
+    b_ = torch.randn(8192, 8192, generator=g, device=device).bfloat16()
+    c_ = torch.empty(8192, 8192, dtype=torch.bfloat16, device=device)
+    with TelemetrySampler(local) as tel:
+        ms = ev_ms(lambda: torch.mm(a_, b_.t(), out=c_), 200)
+    out["library_gemm_tflops"] = 2.0 * 8192 ** 3 / (ms * 1e-3) / 1e12
+    out["library_gemm_shape"] = "8192 x 8192 x 8192 bf16 (torch.mm -> hipBLASLt), N(0, 1) operands, 200 launches"
+    out["library_gemm_telemetry"] = tel.summary()
+    out["idle_telemetry"] = gpu_telemetry(local)
+    out["reference"] = {"library_gemm_tflops": REF_GEMM_TFLOPS, "hbm_copy_GBs": REF_COPY_GBS}
+    return out
+
+
 def _host_mem_gb():
     try:
         for line in open("/proc/meminfo"):
@@ -375,6 +529,7 @@ def main():
                                                           "the profile runs want the headline step's kernels only")
     ap.add_argument("--skip-sp-predict", action="store_true", help="skip the stub-communicator rank of configs[3] (scaling_131k_predicted)")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-box", action="store_true", help="skip the box-calibration probes (HBM copy, MFMA stream, library GEMM)")
     ap.add_argument("--skip-gen", action="store_true")
     ap.add_argument("--steps-131k", type=int, default=2)
     ap.add_argument("--sp-timeout", type=float, default=420.0, help="N > 1: seconds the sequence-parallel 131k leg may take")
@@ -418,8 +573,16 @@ def main():
     ids = acgt_ids(B, nt, 1234 + 1000 * rank, device)
     T = nt + 1
     step_stats = {}
+    box = {}
+    if not args.skip_box:
+        try:
+            box = box_probes(ops, device, local)
+        except Exception as e:  # noqa: BLE001
+            box = {"error": f"{type(e).__name__}: {e}"}
     with torch.inference_mode():
-        dt = timed(lambda: scoring_step(model, ids), args.steps, args.warmup, dist_on, step_stats)
+        with TelemetrySampler(local) as tel_head:
+            dt = timed(lambda: scoring_step(model, ids), args.steps, args.warmup, dist_on, step_stats)
+        box["headline_telemetry"] = tel_head.summary()
         # per-kernel HIP-event timings over a second, separately instrumented pass of the same steps
         ops.timer = KernelTimer()
         for _ in range(args.steps):
@@ -463,7 +626,16 @@ def main():
         "model_tflops": flops_per_token(T) * B * T / (dt / args.steps) / 1e12,
         "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
+        "box": box,
     }
+    if "library_gemm_tflops" in box and "hbm_copy_GBs" in box:
+        share = min(1.0, gemm_ms / (step_stats.get("hip_event_ms_median") or ms_per_step))
+        cal = share * box["library_gemm_tflops"] / REF_GEMM_TFLOPS + (1.0 - share) * box["hbm_copy_GBs"] / REF_COPY_GBS
+        box["dense_share_of_step"] = share
+        box["calibration_factor"] = cal
+        out["value_per_calibrated_box"] = value / cal
+        out["value_per_calibrated_box_note"] = ("value / (dense_share * library_gemm_tflops / 1500 + (1 - dense_share) * hbm_copy_GBs / 6290): the headline "
+                                                "on a box that gives the reference rates; compare THIS across rounds, `value` across code states on one box")
     # ------------------------------------------------------------------ the A/B legs' own reference: the DEFAULT routing timed exactly as the legs are
     # (3 steps behind one warm-up, here and again behind the last leg: the headline's 5 steps were timed minutes earlier in the process and the
     # part's clocks drift by ~1 % meanwhile -- compare a leg with `ab_reference`, not with the headline)
@@ -551,6 +723,19 @@ def main():
             out["ab_reference"]["ms_per_step_after_legs"] = _ab_ref()
         except Exception as e:  # noqa: BLE001
             out["ab_reference"]["error"] = f"{type(e).__name__}: {e}"
+    # ------------------------------------------------------------------ the headline once more, behind the legs (same routing, same steps)
+    if n_gpus == 1 and not args.skip_ab:
+        try:
+            again = {}
+            with torch.inference_mode():
+                with TelemetrySampler(local) as tel2:
+                    dt_again = timed(lambda: scoring_step(model, ids), args.steps, 1, dist_on, again)
+            out["headline_after_legs"] = {"value": B * nt / (dt_again / args.steps), "ms_per_step": dt_again / args.steps * 1e3, "steps": args.steps,
+                                          "step_timing": again, "telemetry": tel2.summary(),
+                                          "note": "the headline configuration timed a second time after the A/B legs (minutes later in the process): the "
+                                                  "spread between the two is this box's drift, not code"}
+        except Exception as e:  # noqa: BLE001
+            out["headline_after_legs"] = {"error": f"{type(e).__name__}: {e}"}
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if rank == 0 and n_gpus == 1 and not args.skip_cpu:
         try:

@@ -24,6 +24,7 @@ EXPORTS = [
     "evo_linear_small_m_bf16", "evo_mlp_gate_small_m_bf16", "evo_norm_mlp_gate_small_m_bf16", "evo_norm_linear_small_m_bf16", "evo_hyena_decode_fused_small_m", "evo_linear_mfma_bf16", "evo_mlp_gate_mfma_bf16", "evo_linear_xblk_mfma_bf16", "evo_hyena_ct", "evo_linear_t_mfma_bf16", "evo_rmsnorm_rows_bf16", "evo_gelu_gate_bf16",
     "evo_logprob_entropy", "evo_unembed_logprob_bf16", "evo_rope_append_decode_bf16",
     "evo_linear_mfma_nf_bf16", "evo_linear_xblk_mfma_nf_bf16", "evo_mlp_gate_mfma_nf_bf16", "evo_linear_t_mfma_nf_bf16", "evo_rms_finalize_f32",
+    "evo_probe_copy_f4", "evo_probe_mfma_bf16",
 ]
 
 

@@ -932,7 +932,7 @@ extern "C" int evo_linear_mfma_nf_bf16(const void* x, const void* w, const void*
     a.tiles_m = (int)((M + GBM - 1) / GBM);
     // raster width: the ~32 tiles an XCD runs at once cover group_m X panels x 32 / group_m W panels.  Measured on the four layer
     // shapes at M = 65,536 (tools/gemm_ab.py lib.so@G): N = 12,288 / 22,016: 8 is best (98.1 / 98.2 % of hipBLASLt against 97.6 /
-    // 96.6 at 4, 88 at 16, 60 at 32); N = 4,096 (16 column tiles): 1-4 tie, 8 loses 1.5-2.5 %.  EVO_GEMM_GROUP_M overrides.
+    // 96.6 at 4, 88 at 16, 60 at 32); N = 4,096 (16 column tiles): 1-4 tie, 8 loses 1.5-2.5 %.
     const int group_m = (a.tiles_n >= 32 ? 8 : 4);
     a.group_m = group_m;
     const int64_t tiles = ((M + GBM - 1) / GBM) * a.tiles_n;
@@ -941,6 +941,7 @@ extern "C" int evo_linear_mfma_nf_bf16(const void* x, const void* w, const void*
     const dim3 grid((unsigned)tiles), block(512);
     hipStream_t st = (hipStream_t)stream;
     static const int form = [] { const char* e = getenv("EVO_GEMM_FORM"); return e ? atoi(e) : 1; }();   // 1: persistent, 0: tile per workgroup
+    if ((row_scale || sumsq) && form != 1) return -1;           // the folded norm exists in the persistent kernel only: never fall through to a launch that ignores it
     if (form == 1 && K >= 2 * GBK && M * K * 2 < 0xffffffffll && N * K * 2 < 0xffffffffll) {
         static const int n_cu = [] {
             int dev = 0, n = 256;

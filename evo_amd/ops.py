@@ -47,6 +47,8 @@ _SIGNATURES = {
     "evo_mlp_gate_mfma_nf_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_t_mfma_nf_bf16": ([_PTR] * 5 + [_I64] * 6 + [_PTR], _c.c_int),
     "evo_rms_finalize_f32": ([_PTR, _I64, _I64, _PTR, _I64, _I64, _I64, _F32, _PTR, _PTR], _c.c_int),
+    "evo_probe_copy_f4": ([_PTR, _PTR, _I64, _PTR], _c.c_int),
+    "evo_probe_mfma_bf16": ([_PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
@@ -58,7 +60,7 @@ _SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 9          # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
+ABI_VERSION = 10         # must equal EVO_ABI_VERSION in include/evo_mi355x.h (bumped on every signature change)
 
 
 class EvoLibraryError(RuntimeError):

@@ -306,7 +306,10 @@ class SequenceParallelScorer:
         return hit
 
     # ------------------------------------------------------------------ blocks
-    def _hyena_block(self, blk, x2d, B, Tloc, Tl, T):
+    def _hyena_block(self, blk, x2d, B, Tloc, Tl, T, rs=None):
+        """`rs`: 1 / (rms + eps) of every row of x2d from the epilogue of the dense layer that wrote it (round 6: the shards fold their
+        RMSNorm passes into the dense layers exactly as the single-GPU forward does, sh/model.py `_nf_ok`), or None: this block norms for
+        itself.  Returns the next block's `rs` (or None)."""
         m, ops = self.m, self.m.ops
         D, H = m.hidden_size, m.num_heads
         f = blk.filter
@@ -325,8 +328,13 @@ class SequenceParallelScorer:
             and m._mfma_hyena_ok(nb_min, Tl) and ops.zt_shape_ok(B, Tl, 3 * D, D) and ops.zt_shape_ok(B, t_min, 3 * D, D) and t_min >= 2
         w_p, b_p = blk.projections.weight.data, (None if blk.projections.bias is None else blk.projections.bias.data)
         table = m._mfma_table(blk) if ztm else None
-        if ztm:
-            n1 = None
+        # norms folded into the dense layers (a rank-local choice: no collective depends on it -- the last, shorter shard may differ)
+        nf = ztm and m._nf_ok(B * Tloc, None)
+        stream_rows = nf and rs is not None and ops.zt_stream_rows_ok(B, Tloc)   # the projection reads the residual stream itself
+        xp = n1 = None
+        if stream_rows:
+            pass
+        elif ztm:
             xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, m.eps, B, Tloc)      # rows in z^T's position order
         else:
             n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
@@ -336,14 +344,19 @@ class SequenceParallelScorer:
         if self.world > 1:
             if Tloc >= 2:
                 if ztm:
-                    rows = ops.rmsnorm(x2d.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D).contiguous(), None, blk.pre_norm.scale, m.eps)
+                    # (norm + projection of the 2 B halo rows: ONE weight-streaming launch up to 8 rows at D = 4096, else norm + launch)
+                    xh = x2d.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D).contiguous()
+                    parts = [ops.norm_linear(xh[i:i + 8], blk.pre_norm.scale, m.eps, w_p, b_p) for i in range(0, 2 * B, 8)]   # (8 rows per fused launch)
+                    tail = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).view(B, 2, 3 * D)
                 else:
-                    rows = n1.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D)
-                tail = ops.linear(rows, w_p, b_p).view(B, 2, 3 * D)
+                    tail = ops.linear(n1.view(B, Tloc, D)[:, -2:, :].reshape(B * 2, D), w_p, b_p).view(B, 2, 3 * D)
                 halo, halo_w = self._shift(tail)
             else:                                            # (last rank only, see check_geometry: nobody reads it)
                 halo, halo_w = self._shift(x2d.new_zeros(B, 2, 3 * D))
-        if ztm:
+        if stream_rows:
+            wp_f = m._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
+            z = ops.linear_t_rs(x2d, rs, wp_f, b_p, w_p, blk.pre_norm.scale, m.eps, B, Tloc)
+        elif ztm:
             z = ops.linear_t(xp, w_p, b_p, B, Tloc)          # z^T [blocks, 3 D, 256]
         else:
             z = ops.linear(n1, w_p, b_p).view(B, Tloc, 3 * D)
@@ -397,26 +410,39 @@ class SequenceParallelScorer:
                 y[b0:b1] = yg
             else:
                 y = yg
+        if nf:
+            # output projection with the post-norm's statistic out of its epilogue, gated MLP with the factor in its epilogue, l3 with the
+            # NEXT block's statistic: no RMSNorm pass, no gate kernel (sh/model.py: _mixer_out_rs_ / _mlp_residual_rs_)
+            return m._mlp_residual_rs_(blk, x2d, m._mixer_out_rs_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias))
         if ztm:
             ops.linear_residual_yblk_(x2d, y, blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)
         else:
             ops.linear_residual_(x2d, y.view(B * Tloc, D), blk.out_filter_dense.weight, bias=blk.out_filter_dense.bias)
         m._mlp_residual_(blk, x2d, None)                     # (the bias went into the output projection's epilogue, as in model.py)
+        return None
 
-    def _attn_block(self, blk, x2d, B, Tloc, Tl, t0, T):
+    def _attn_block(self, blk, x2d, B, Tloc, Tl, t0, T, rs=None):
         m, ops = self.m, self.m.ops
         D, H, hd = m.hidden_size, m.num_heads, m.head_dim
         mha = blk.inner_mha_cls
-        n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
-        qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, Tloc, 3, H, hd)
+        nf = m._nf_ok(B * Tloc, None)
+        if nf and rs is not None:
+            wqkv_f = m._folded(mha, "_wqkv_f", mha.Wqkv.weight, blk.pre_norm.scale)
+            qkv = ops.linear_rs(x2d, rs, wqkv_f, mha.Wqkv.bias, mha.Wqkv.weight, blk.pre_norm.scale, m.eps).view(B, Tloc, 3, H, hd)
+        else:
+            n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
+            qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, Tloc, 3, H, hd)
         cos, sin = m._rotary(t0, Tloc, x2d.device)
         ops.rope_(qkv, cos, sin)
         if self.attn_mode != "allgather" and H % self.world == 0 and hasattr(self.comm, "all_to_all"):
             a = self._attn_ulysses(qkv, B, Tloc, Tl, T)
         else:
             a = self._attn_allgather(qkv, B, Tloc, Tl, t0)
+        if nf:
+            return m._mlp_residual_rs_(blk, x2d, m._mixer_out_rs_(blk, x2d, a.view(B * Tloc, D), mha.out_proj.weight, mha.out_proj.bias))
         ops.linear_residual_(x2d, a.view(B * Tloc, D), mha.out_proj.weight, mfma=True, bias=mha.out_proj.bias)
         m._mlp_residual_(blk, x2d, None)
+        return None
 
     def _attn_ulysses(self, qkv, B, Tloc, Tl, T):
         """Batch rows travel in `attn_row_groups` groups: ONE all-to-all and ONE attention launch (rows x H/R heads) per group
@@ -507,11 +533,12 @@ class SequenceParallelScorer:
         ops = m.ops
         # (checked above, on every rank: no second check -- and no shared flag toggled, ranks may be threads of one process in tests)
         h = ops.embed(ids_full[:, t0:t1].contiguous().to(m.device), m.embedding_layer.weight, validate=False)
+        rs = None                                           # row factors handed from block to block (None: the block norms for itself)
         for blk in m.blocks:
             if isinstance(blk, _AttentionBlock):
-                self._attn_block(blk, h, B, Tloc, Tl, t0, T)
+                rs = self._attn_block(blk, h, B, Tloc, Tl, t0, T, rs)
             else:
-                self._hyena_block(blk, h, B, Tloc, Tl, T)
+                rs = self._hyena_block(blk, h, B, Tloc, Tl, T, rs)
         if m.norm is not None:
             h = ops.rmsnorm(h, None, m.norm.scale, m.eps)
         return h

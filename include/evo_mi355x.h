@@ -41,8 +41,9 @@ extern "C" {
  *      fed them: every caller is on evo_hyena_ct).
  *   9: the RMSNorm passes folded into the dense layers around them: evo_linear_mfma_nf_bf16, evo_linear_xblk_mfma_nf_bf16,
  *      evo_mlp_gate_mfma_nf_bf16, evo_linear_t_mfma_nf_bf16 (the same launches with a per-row factor in / the rows' sums of squares
- *      out) and evo_rms_finalize_f32 added; no signature changed. */
-#define EVO_ABI_VERSION 9
+ *      out) and evo_rms_finalize_f32 added; no signature changed.
+ *  10: evo_probe_copy_f4 and evo_probe_mfma_bf16 added (the box-calibration probes of bench.py's `box` block); no signature changed. */
+#define EVO_ABI_VERSION 10
 int evo_abi_version(void);
 
 /* ---- embedding gather ------------------------------------------------------------------------
@@ -323,6 +324,17 @@ int evo_logprob_entropy(const void* logits, int64_t logits_f32, const int64_t* t
  * and the softmax statistics are taken in fp32 on the rounded values.  V must be 512, K % 32 == 0. */
 int evo_unembed_logprob_bf16(const void* hidden, const void* emb, const int64_t* target,
                              float* logprob, float* entropy, int64_t M, int64_t V, int64_t K, void* stream);
+
+/* ---- box-calibration probes (measurement infrastructure; no reference counterpart) -----------------------------------
+ * Two FIXED kernels whose rates depend on the box (HBM, the clocks its power cap allows) and on nothing else in this library:
+ * bench.py times them in the same process right before the headline so that a driver-timed number can be compared across
+ * boxes and rounds.
+ *   evo_probe_copy_f4:   dst[i] = src[i], 16 bytes per lane, grid-stride (nbytes % 16 == 0): the guide's "float4 copy".
+ *   evo_probe_mfma_bf16: n_blocks workgroups of 4 waves (one per SIMD), each wave `iters` trips of 16 independent
+ *                        v_mfma_f32_16x16x32_bf16 on register-resident pseudo-random bf16 operands (never zeros);
+ *                        flop = n_blocks * 4 * iters * 16 * 16384.  out [n_blocks * 256] fp32 sink or NULL. */
+int evo_probe_copy_f4(const void* src, void* dst, int64_t nbytes, void* stream);
+int evo_probe_mfma_bf16(float* out, int64_t n_blocks, int64_t iters, void* stream);
 
 #ifdef __cplusplus
 }

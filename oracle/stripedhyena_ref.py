@@ -199,6 +199,8 @@ class RefStripedHyena:
         self.mode = mode
         self.dev = torch.device("cpu" if device is None else device)
         self.rotary_table_bf16 = rotary_table_bf16
+        self.attn_chunk_elems = 1 << 24      # score-tile bound of `attention` (elements); GPU executions at long T raise it
+        self.chan_chunk = None               # channels per filter / FFT evaluation in `hyena_filter_parallel` (None: all at once)
         self.act = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp64": torch.float64}[mode]
         self.hi = torch.float64 if mode == "fp64" else torch.float32   # filter / FFT / state precision
         self.w: Dict[str, torch.Tensor] = {}
@@ -233,9 +235,10 @@ class RefStripedHyena:
         r = torch.view_as_complex(self.w[pre + "filter.residues"].reshape(-1, self.cfg.state_size, 2).contiguous())
         return p, r
 
-    def compute_filter(self, pre, T: int) -> torch.Tensor:
-        """upstream ParallelHyenaFilter.compute_filter: h[d,t] = Re sum_s R[d,s] * exp(t*log p[d,s])."""
+    def compute_filter(self, pre, T: int, c0: int = 0, c1: Optional[int] = None) -> torch.Tensor:
+        """upstream ParallelHyenaFilter.compute_filter: h[d,t] = Re sum_s R[d,s] * exp(t*log p[d,s])  (channels c0..c1)."""
         p, r = self.poles_residues(pre)
+        p, r = p[c0:c1], r[c0:c1]
         t = torch.arange(T, dtype=self.hi, device=self.dev)
         logp = torch.log(p)
         h = (r[..., None] * torch.exp(logp[..., None] * t)).real.sum(1)      # [D,T]
@@ -279,8 +282,16 @@ class RefStripedHyena:
         x2, x1, v = self.column_split(zc)
         x1v = x1 * v
         T = x1v.shape[-1]
-        h = self.compute_filter(pre, T)
-        y = self.fftconv(x1v, h).to(x1v.dtype)
+        if self.chan_chunk is None:
+            h = self.compute_filter(pre, T)
+            y = self.fftconv(x1v, h).to(x1v.dtype)
+        else:
+            # the same two statements, `chan_chunk` channels at a time: the filter [D, 8, T] complex is 34 GB at T = 131,073 in
+            # fp32 with three temporaries of that size around it -- long inputs on the GPU bound it this way
+            y = torch.empty_like(x1v)
+            for c0 in range(0, x1v.shape[1], self.chan_chunk):
+                c1 = min(x1v.shape[1], c0 + self.chan_chunk)
+                y[:, c0:c1] = self.fftconv(x1v[:, c0:c1], self.compute_filter(pre, T, c0, c1)).to(x1v.dtype)
         Dskip = self.w[pre + "filter.D"]
         y = (y + x1v * Dskip[None, :, None]) * x2
         state = None
@@ -345,21 +356,23 @@ class RefStripedHyena:
         out = torch.empty_like(q)
         qi = torch.arange(Tq, device=self.dev)[:, None] + q_pos0
         kj = torch.arange(Tk, device=self.dev)[None, :]
-        mask = kj > qi
-        chunk = max(1, min(Tq, (1 << 24) // max(1, Tk)))
+        # query rows are taken in chunks of `attn_chunk_elems / Tk` (bounds the [chunk, Tk] score tile); a chunk only looks at the keys
+        # up to its last row's position (the keys beyond are masked to exp(-inf) = 0 exactly: same softmax, half the work at long T)
+        chunk = max(1, min(Tq, self.attn_chunk_elems // max(1, Tk)))
         for h in range(H):
             for b in range(B):
                 kk = k[b, :, h].to(self.hi)
                 vv = v[b, :, h]
                 for s0 in range(0, Tq, chunk):
                     s1 = min(Tq, s0 + chunk)
-                    sc = (q[b, s0:s1, h].to(self.hi) @ kk.T) / math.sqrt(hd)
-                    sc = sc.masked_fill(mask[s0:s1], float("-inf"))
+                    kmax = min(Tk, q_pos0 + s1)
+                    sc = (q[b, s0:s1, h].to(self.hi) @ kk[:kmax].T) / math.sqrt(hd)
+                    sc = sc.masked_fill(kj[:, :kmax] > qi[s0:s1], float("-inf"))
                     pr = torch.softmax(sc, dim=-1)
                     if self.mode == "bf16":
-                        o = (pr.to(torch.bfloat16).float() @ vv.float()).to(q.dtype)
+                        o = (pr.to(torch.bfloat16).float() @ vv[:kmax].float()).to(q.dtype)
                     else:
-                        o = (pr @ vv.to(self.hi)).to(q.dtype)
+                        o = (pr @ vv[:kmax].to(self.hi)).to(q.dtype)
                     out[b, s0:s1, h] = o
         return out
 

@@ -130,7 +130,7 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
     # ---- every block teacher-forced, WITH the oracle's caches: the prompt pass, then every decode step -------------------
     t0 = time.time()
     worst = {"hyena": [0.0, 0.0, 0.0], "attn": [0.0, 0.0, 0.0]}
-    state_rel = state_floor = fir_max = kv_rel = 0.0
+    state_rel = state_floor = fir_max = fir_over = kv_rel = 0.0
     bad = []                                                   # (every measurement is printed before anything is asserted)
     for i in range(32):
         kind = "attn" if i in attn_idx else "hyena"
@@ -148,7 +148,9 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
             state_rel = max(state_rel, ((se - sr).norm() / sr.norm()).item())
             state_floor = max(state_floor, ((sf - sr).norm() / sr.norm()).item())
             fe, fr = cache["fir"][i].double(), oc["hyena"].fir_state_dict[i].double()
-            fir_max = max(fir_max, ((fe - fr).abs() / (fr.abs() * 2.0 ** -8 + fr.abs().max() * 2e-3)).max().item())
+            fratio = (fe - fr).abs() / (fr.abs() * 2.0 ** -8 + fr.abs().max() * 2e-3)
+            fir_max = max(fir_max, fratio.max().item())
+            fir_over = max(fir_over, (fratio > 1.0).double().mean().item())       # share of a layer's FIR-history elements beyond the bound
         else:
             ke = cache["cache"]["mha"].key_value_memory_dict[i][:1, :P].double()     # (rows 0..P-1: untouched by the decode steps)
             kr = oc["mha"].key_value_memory_dict[i][:1, :P].double()
@@ -180,7 +182,11 @@ def test_configs4_cached_prefill_and_graph_decode_vs_fp32_oracle(full):
     # the end state sums 8,192 inputs x1 * v that carry the bf16 rounding of z: judged against what the reference's own arithmetic does
     # (FIR history = two bf16 rows of z per layer: an element on the other side of a rounding boundary is one ulp = up to 2^-7 |ref| off,
     #  i.e. up to ~1.3 in units of the bound; anything beyond a single flip would show as >= 2)
-    assert state_rel <= max(1.25 * state_floor, 4e-3) and fir_max <= 1.35 and kv_rel <= 4e-3, (state_rel, state_floor, fir_max, kv_rel)
+    # (1.35 alone cannot tell one flip from a small systematic drift of the folded norm -- so the SHARE of elements beyond the
+    #  bound is pinned too: isolated flips are a few in 24,576 per layer; a drift would move whole rows)
+    print(f"[configs4 prompt pass] FIR history: worst {fir_max:.2f} of the bound, share of elements beyond it {fir_over:.2e}")
+    assert state_rel <= max(1.25 * state_floor, 4e-3) and fir_max <= 1.35 and fir_over <= 1e-3 and kv_rel <= 4e-3, \
+        (state_rel, state_floor, fir_max, fir_over, kv_rel)
 
     # ---- end to end: the oracle's own cached path, fed the engine's tokens; the eager-bf16 restatement beside it ---------------
     def oracle_run(orc):

@@ -1,0 +1,290 @@
+"""GPU (-m gpu): parity at the sizes and on the parameters the north-star sentence names (round 6).
+
+ (a) END TO END at BASELINE configs[2]: the 1 x 131,073-token scoring forward of the 131k yml (rotary / 16) on the trained-like
+     ("contractive") weights -- engine default routing (norms folded) and `fuse_norm = False` -- against the oracle's fp32 forward and
+     its eager-bf16 forward (= the reference's own arithmetic), both executed on the GPU by torch's eager kernels (oracle/ is the
+     checker; nothing of libevo_mi355x.so runs in it).  What the reference runs there: /root/reference/evo/scoring.py:77-84 on
+     /root/reference/evo/configs/evo-1-131k-base_inference.yml:33,37,39-40.  Same for two FULL rows of the 8 x 8,193 batch (configs[1]).
+ (b) a PARAMETER-REGIME sweep of the Hyena operator kernels (hyena_ct through its bf16 hi/lo operand tables, and the modal three-launch
+     path) against the fp64 FFT form: pole moduli from 1e-2 (upstream's init) to exactly 1, residues from 1e-2 to 30 including mode
+     pairs that cancel to 1 %, input and FIR scales from 1e-2 to 30.  Real checkpoints keep poles / residues in fp32 for a reason
+     [REF evo/models.py:146-148]; the synthetic law of every other test (|p| = 1 - 10^U(-5,-1), residues ~ sqrt(1 - |p|)) is one point
+     of that space.
+"""
+import math
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stripedhyena_ref as R
+from conftest import contractive_oracle
+from gpu_ref64 import gpu_fft_hyena
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+FULL = dict(vocab_size=512, hidden_size=4096, num_layers=32, attn_layer_idxs=[8, 16, 24], num_attention_heads=32)
+FULL_131K = dict(FULL, use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+
+
+def acgt_ids(B, L, seed=1234):
+    rows = [np.random.default_rng(seed + b).choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L) for b in range(B)]
+    ids = torch.from_numpy(np.stack(rows).astype(np.int64))
+    return torch.cat([torch.zeros(B, 1, dtype=torch.long), ids], dim=1)
+
+
+def score_rows(logits, ids):
+    """per-sequence mean log-prob of the next token [REF evo/scoring.py:84-96], in fp64 on the logits' device."""
+    lsm = torch.log_softmax(logits.double()[:, :-1], -1)
+    return lsm.gather(-1, ids.to(logits.device)[:, 1:, None].long()).squeeze(-1).mean(-1).cpu()
+
+
+def rel_l2_rows(a, ref):
+    a, ref = a.double(), ref.double()
+    return ((a - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).cpu()
+
+
+_oracle = contractive_oracle
+
+
+def _engine_logits(m, ids, fuse_norm):
+    was = m.ops.fuse_norm
+    m.ops.fuse_norm = fuse_norm
+    try:
+        out = m(ids.to(DEV))[0].float()
+        torch.cuda.synchronize()
+        return out
+    finally:
+        m.ops.fuse_norm = was
+
+
+def test_contractive_weights_come_from_the_pinned_table_and_contract(contractive):
+    """The parity weights are a pure function of (seed, dims, evo_amd/configs/contractive_gains.json) -- no engine run builds them
+     -- and on today's engine every block past the first still changes the stream by ~7 % of its norm."""
+    from evo_amd.synthetic import pinned_contractive_gains
+    m = contractive["m8"]
+    gains = pinned_contractive_gains(m, 0)
+    assert gains is not None and sorted(gains) == list(range(1, 32))
+    ids = acgt_ids(1, 512, seed=99)
+    m.block_taps = []
+    try:
+        m(ids.to(DEV))
+        taps = [t.float() for t in m.block_taps]
+    finally:
+        m.block_taps = None
+    ratios = [float((taps[i + 1] - taps[i]).norm() / taps[i].norm()) for i in range(32)]
+    print(f"[contractive, pinned gains] block update / stream norm: block 0 {ratios[0]:.2f}, blocks 1..31 min {min(ratios[1:]):.4f} max {max(ratios[1:]):.4f}")
+    assert 0.06 <= min(ratios[1:]) and max(ratios[1:]) <= 0.08
+
+
+# measured on MI355X (round 6, tests/PARITY.md rows 4a / 4b); the north-star's 1e-3 is asserted on the SCORE of every sequence
+PIN_SCORE = 1.0e-3
+
+
+def test_contractive_1x131073_scoring_forward_end_to_end_vs_fp32_oracle(contractive):
+    """(a) BASELINE configs[2], end to end, at the north-star's own size: logits [1, 131073, 512] and the sequence score of the engine's
+    DEFAULT routing and of `fuse_norm = False`, vs the oracle's fp32 forward; the oracle's eager-bf16 forward beside it as the floor."""
+    T = 131073
+    ids = acgt_ids(1, T - 1)
+    m = contractive["m131"]
+    got = {True: _engine_logits(m, ids, True), False: _engine_logits(m, ids, False)}
+    assert got[True].shape == (1, T, 512) and torch.isfinite(got[True]).all() and torch.isfinite(got[False]).all()
+    m.ops.release_workspaces()
+    t0 = time.time()
+    ref = _oracle(contractive, FULL_131K, "fp32")(ids)[0].float()
+    torch.cuda.synchronize()
+    t32 = time.time() - t0
+    t0 = time.time()
+    flo = _oracle(contractive, FULL_131K, "bf16")(ids)[0].float()
+    torch.cuda.synchronize()
+    t16 = time.time() - t0
+    assert ref.std() > 0.1
+    s_ref, s_flo = score_rows(ref, ids), score_rows(flo, ids)
+    e_flo, r_flo = rel_l2_rows(flo, ref).item(), ((s_flo - s_ref).abs() / s_ref.abs()).item()
+    print(f"[131k end to end, contractive] oracle on the GPU: fp32 {t32:.0f} s, eager-bf16 {t16:.0f} s; logits std {ref.std().item():.2f}; "
+          f"score fp32 {s_ref.item():.6f}; eager-bf16 reference arithmetic: logits rel-L2 {e_flo:.3e}, score rel {r_flo:.2e}")
+    # where along the sequence the error sits: first / middle / last 8,192 positions
+    for fold in (True, False):
+        g = got[fold]
+        e = rel_l2_rows(g, ref).item()
+        s = score_rows(g, ids)
+        r = ((s - s_ref).abs() / s_ref.abs()).item()
+        seg = [rel_l2_rows(g[:, a:a + 8192], ref[:, a:a + 8192]).item() for a in (0, 61440, T - 8192)]
+        amax = ((g - ref).abs().max() / ref.abs().max()).item()
+        print(f"[131k end to end, contractive] engine ({'norms folded: default' if fold else 'fuse_norm = False'}): logits rel-L2 {e:.3e} "
+              f"(first / middle / last 8,192 positions {seg[0]:.3e} / {seg[1]:.3e} / {seg[2]:.3e}), max |delta| / max |ref| {amax:.2e}, "
+              f"score {s.item():.6f} rel {r:.2e}")
+        assert r <= PIN_SCORE, (fold, r)
+        assert e <= 1.1 * e_flo and e <= 3.0e-2, (fold, e, e_flo)
+
+
+def test_contractive_two_full_rows_of_the_8x8193_batch_vs_fp32_oracle(contractive):
+    """(a) BASELINE configs[1]: the 8 x 8,193 batch on the engine (default and fuse_norm = False); rows 0 and 5 in FULL (all 8,193
+    positions) vs the oracle's fp32 and eager-bf16 forwards of those two rows."""
+    ids = acgt_ids(8, 8192)
+    rows = [0, 5]
+    m = contractive["m8"]
+    got = {f: _engine_logits(m, ids, f)[rows] for f in (True, False)}
+    sub = ids[rows]
+    ref = _oracle(contractive, FULL, "fp32")(sub)[0].float()
+    flo = _oracle(contractive, FULL, "bf16")(sub)[0].float()
+    s_ref, s_flo = score_rows(ref, sub), score_rows(flo, sub)
+    e_flo, r_flo = rel_l2_rows(flo, ref), (s_flo - s_ref).abs() / s_ref.abs()
+    print(f"[8x8193 rows {rows}, contractive] eager-bf16 reference arithmetic: logits rel-L2 {e_flo.tolist()}, score rel {r_flo.tolist()}")
+    for fold in (True, False):
+        e = rel_l2_rows(got[fold], ref)
+        r = (score_rows(got[fold], sub) - s_ref).abs() / s_ref.abs()
+        print(f"[8x8193 rows {rows}, contractive] engine ({'norms folded: default' if fold else 'fuse_norm = False'}): logits rel-L2 "
+              f"{[f'{x:.3e}' for x in e.tolist()]}, score rel {[f'{x:.2e}' for x in r.tolist()]}")
+        assert (r <= PIN_SCORE).all(), (fold, r)
+        assert (e <= 1.1 * e_flo).all() and (e <= 3.0e-2).all(), (fold, e, e_flo)
+
+
+# ---- (b) parameter regimes of the Hyena operator ---------------------------------------------------------------------------------------
+P_MODS = (1e-2, 0.5, 0.9, 1.0 - 1e-6, 1.0)
+R_LAWS = ("1e-2", "1", "30", "cancel")              # residue scale; "cancel": scale 30, modes in pairs that cancel to 1 %
+SCALES = (1e-2, 1.0, 30.0)                          # input (z) and FIR-tap scales
+
+
+def _regime_inputs(B, T, z_scale, fir_scale, seed):
+    """D = 4096 channels in 256 groups of 16; group gidx takes regime (gidx % 20): pole modulus P_MODS[r % 5], residue law R_LAWS[r // 5].
+    Phases uniform.  Returns z, the operator's parameters and the regime index of every channel."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    D, H = 4096, 32
+    z = (torch.randn(B, T, 3 * D, generator=g, device=DEV) * z_scale).bfloat16()
+    fir_w = (torch.randn(3 * D, 3, generator=g, device=DEV) * 0.3 * fir_scale).bfloat16()
+    fir_b = (torch.randn(3 * D, generator=g, device=DEV) * 0.1 * fir_scale * z_scale).bfloat16()
+    reg = (torch.arange(D, device=DEV) // 16) % (len(P_MODS) * len(R_LAWS))
+    mag = torch.tensor(P_MODS, device=DEV, dtype=torch.float64)[reg % len(P_MODS)][:, None].expand(D, 8)
+    ang = (torch.rand(D, 8, generator=g, device=DEV, dtype=torch.float64) * 2 - 1) * math.pi
+    law = reg // len(P_MODS)
+    rscale = torch.tensor([1e-2, 1.0, 30.0, 30.0], device=DEV, dtype=torch.float64)[law]
+    res = torch.randn(D, 8, 2, generator=g, device=DEV, dtype=torch.float64) * rscale[:, None, None]
+    cancel = law == 3
+    # cancelling pairs: mode 2k+1 = the conjugate-free NEGATIVE of mode 2k up to 1 % (same pole up to 1e-3 in phase), so that the filter is
+    # the small difference of two large, nearly equal mode sums
+    angc = ang.clone()
+    angc[:, 1::2] = ang[:, 0::2] + 1e-3
+    ang = torch.where(cancel[:, None], angc, ang)
+    resc = res.clone()
+    resc[:, 1::2] = -0.99 * res[:, 0::2]
+    res = torch.where(cancel[:, None, None], resc, res)
+    poles = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang)], -1).float().contiguous()
+    dskip = (torch.randn(D, generator=g, device=DEV) * 0.5).bfloat16()
+    return z, (fir_w, fir_b, poles, res.float().contiguous(), dskip, H), reg
+
+
+@pytest.mark.parametrize("shape", [(2, 2051, "tail"), (1, 5003, "padded")])
+def test_hyena_operator_parameter_regimes_vs_fft(shape):
+    """20 (pole modulus, residue law) regimes x 9 (input scale, FIR scale) pairs through hyena_ct (both forms of z^T) and the modal
+    launches vs the fp64 FFT long convolution; judged per regime: every output inside one bf16 rounding of the fp64 value (+ 2e-3 of the
+    channel's largest output), rel-L2 no worse than the reference's eager-bf16 arithmetic on the same inputs, end state to 1e-4 of
+    the channel's largest component."""
+    from evo_amd.hyena_tables import mfma_operand_table
+    from evo_amd.ops import HipOps
+    B, T, form = shape
+    ops = HipOps()
+    D = 4096
+    nreg = len(P_MODS) * len(R_LAWS)
+    worst = {}
+    bad = []
+    t0 = time.time()
+    for zi, zs in enumerate(SCALES):
+        for fi, fs in enumerate(SCALES):
+            z, prm, reg = _regime_inputs(B, T, zs, fs, 100 + 10 * zi + fi)
+            fir_w, fir_b, poles, res, dskip, H = prm
+            ry, rst = gpu_fft_hyena(z, *prm)
+            rfloor, _ = gpu_fft_hyena(z, *prm, ref_rounding=True, want_state=False)
+            assert torch.isfinite(ry).all() and torch.isfinite(rst.real).all()
+            cmax = ry.abs().amax(dim=(0, 1))                                        # [D] the channel's largest output
+            bound = ry.abs() * 2 ** -8 + cmax * 2e-3
+            smax = rst.abs().amax(dim=(0, 2))                                       # [D]
+            table = mfma_operand_table(poles, res, dskip)
+            Tm, Tp, Mp, r = ops.zt_layout(B, T)
+            assert (r > 0) == (form == "tail") and ops.zt_shape_ok(B, T, 3 * D, D)
+            for path in ("hyena_ct", "modal"):
+                if path == "modal":
+                    y, st = ops.hyena_prefill(z, *prm, want_state=True)
+                else:
+                    zt = ops.zt_from_rows(z, B, T, pad_value=float("nan"))
+                    yb, st = ops.hyena_ct(zt, B, T, fir_w, fir_b, table, H, want_state=True, poles=poles, y_blk=ops.yblk_empty(B * T, D, z.device))
+                    y = ops.yblk_to_rows(yb, B * T).view(B, T, D)
+                yd = y.double()
+                assert torch.isfinite(yd).all(), (path, zs, fs)
+                err = (yd - ry).abs()
+                exc = ((err - bound) / cmax.clamp_min(1e-300)).amax(dim=(0, 1))     # [D] worst excess over the bound, in units of the channel's scale
+                serr = ((st.to(torch.complex128) - rst).abs().amax(dim=(0, 2)) / smax.clamp_min(1e-300))   # [D]
+                for k in range(nreg):
+                    sel = reg == k
+                    rl2 = ((yd[..., sel] - ry[..., sel]).norm() / ry[..., sel].norm()).item()
+                    fl2 = ((rfloor[..., sel] - ry[..., sel]).norm() / ry[..., sel].norm()).item()
+                    ex, se = exc[sel].max().item(), serr[sel].max().item()
+                    key = (path, P_MODS[k % len(P_MODS)], R_LAWS[k // len(P_MODS)])
+                    w = worst.get(key, (0.0, 0.0, -1.0, 0.0))
+                    worst[key] = (max(w[0], rl2), max(w[1], rl2 / fl2), max(w[2], ex), max(w[3], se))
+                    if not (ex <= 0.0 and rl2 <= 2.2e-3 and rl2 <= 1.05 * fl2 and se <= 1e-4):
+                        bad.append((path, zs, fs, key[1], key[2], rl2, fl2, ex, se))
+            del ry, rst, rfloor, z
+    print(f"[hyena regimes {B}x{T} {form}] 20 regimes x 9 scale pairs x 2 paths in {time.time() - t0:.0f} s; per regime (worst over the scale pairs): "
+          f"y rel-L2 | rel-L2 / eager-bf16 floor | excess over the bf16 bound | end-state err / channel max")
+    for path in ("hyena_ct", "modal"):
+        for law in R_LAWS:
+            print(f"[hyena regimes] {path:8s} residues {law:6s}: " + "  ".join(
+                f"|p|={pm:g}: {worst[(path, pm, law)][0]:.2e} {worst[(path, pm, law)][1]:.2f} {worst[(path, pm, law)][2]:+.1e} {worst[(path, pm, law)][3]:.1e}"
+                for pm in P_MODS))
+    assert not bad, bad[:12]
+
+
+# ---- (c) the sequence-parallel rank runs the single-GPU forward's fused launches -------------------------------------------------------
+SP4 = dict(vocab_size=512, hidden_size=4096, num_layers=4, attn_layer_idxs=[1], num_attention_heads=32,
+           use_interpolated_rotary_pos_emb=True, rotary_emb_scaling_factor=16)
+
+
+@pytest.mark.parametrize("rank", [3, 7])
+def test_sequence_parallel_rank_launch_counts_and_parity_with_the_unfolded_routing(rank):
+    """BASELINE configs[3] geometry (8 ranks, 8 batch rows, 16,385-token shards; rank 7: the shorter last shard of 16,378 tokens) at D = 4096,
+    4 layers (Hyena / attention / Hyena / Hyena), one rank behind the stub communicator (evo_amd.sp.StubComm: the kernels of a rank, exchanged
+    values meaningless but IDENTICAL between the two routings).  Round 6: the shards fold their RMSNorm passes and the gate into the dense
+    layers like the single-GPU forward -- asserted here as launch counts (<= 2 + 1 `rmsnorm`, 0 `gelu_gate`, 2 `rms_finalize`
+    per block) and as agreement of the rank's log-probs with the same rank under `fuse_norm = False` (65 separate passes) to bf16 noise."""
+    from evo_amd.ops import KernelTimer
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.sp import SequenceParallelScorer, StubComm
+    from evo_amd.synthetic import synthetic_state_dict
+    world, B, T = 8, 8, 131073
+    m = StripedHyena(dict(SP4))
+    m.load_state_dict(synthetic_state_dict(m, seed=3, device=DEV), strict=True)
+    m.to_bfloat16_except_poles_residues()
+    m = m.to(DEV)
+    ops = m.ops
+    ids = acgt_ids(B, T - 1).to(DEV)
+    res = {}
+    for fold in (True, False):
+        was = ops.fuse_norm
+        ops.fuse_norm = fold
+        ops.timer = KernelTimer()
+        try:
+            sc = SequenceParallelScorer(m, rank, world, comm=StubComm(world))
+            with torch.inference_mode():
+                lp = sc.score_logprobs(ids)
+            torch.cuda.synchronize()
+            res[fold] = (lp.double().cpu(), {k: n for k, (n, _) in ops.timer.summary().items()})
+        finally:
+            ops.fuse_norm = was
+            ops.timer = None
+    (lp_f, k_f), (lp_u, k_u) = res[True], res[False]
+    print(f"[sp rank {rank} of 8, 4 layers] launches folded: {k_f}")
+    print(f"[sp rank {rank} of 8, 4 layers] launches fuse_norm = False: {k_u}")
+    # folded: block 0's pre-norm (+ on the last, shorter shard one pre-norm per Hyena block: its z^T has pad positions, the projection cannot
+    # read the stream's rows directly) + the final norm; no gate kernel, no separate sliver gate
+    assert k_f.get("gelu_gate", 0) == 0, k_f
+    assert k_f.get("rms_finalize", 0) == 8, k_f
+    assert k_f.get("rmsnorm", 0) <= (2 if rank < 7 else 4), k_f
+    assert k_u.get("rmsnorm", 0) >= 9 and k_u.get("rms_finalize", 0) == 0, k_u
+    d = (lp_f - lp_u).abs()
+    rel = abs(lp_f.mean() - lp_u.mean()) / abs(lp_u.mean())
+    print(f"[sp rank {rank} of 8, 4 layers] log-probs folded vs separate norms: mean |diff| {d.mean().item():.3e}, max {d.max().item():.3e}, "
+          f"mean log-prob rel {rel.item():.2e}")
+    assert torch.isfinite(lp_f).all() and d.mean().item() < 2e-2 and rel.item() < 2e-3

@@ -88,3 +88,20 @@ def test_fasta_and_buckets(tmp_path):
     assert recs == [("a", "ACGTAC"), ("b", "GG"), ("empty", ""), ("c", "TTTTTTTT")]
     b = length_buckets([s for _, s in recs], 2)
     assert b == [[3, 0], [1, 2]]
+
+
+def test_contractive_profile_is_pinned_for_the_7b_dims():
+    """The trained-like parity weights are a pure function of (seed, dims, evo_amd/configs/contractive_gains.json): no engine run builds
+    them.  The table covers blocks 1..31 of the 7B dims at seed 0, other (seed, dims) fall back to the calibration."""
+    import types
+
+    import torch
+    from evo_amd.synthetic import apply_contractive_gains, pinned_contractive_gains
+    m7 = types.SimpleNamespace(hidden_size=4096, num_layers=32, num_heads=32, inner_size=10928, attn_layer_idxs=[8, 16, 24])
+    g = pinned_contractive_gains(m7, 0)
+    assert g is not None and sorted(g) == list(range(1, 32)) and all(0.02 < v < 0.2 for v in g.values())
+    assert pinned_contractive_gains(m7, 1) is None
+    assert pinned_contractive_gains(types.SimpleNamespace(hidden_size=512, num_layers=4, num_heads=4, inner_size=1376, attn_layer_idxs=[2]), 0) is None
+    sd = {"blocks.1.mlp.l3.weight": torch.ones(4, 4, dtype=torch.bfloat16), "blocks.1.mlp.l1.weight": torch.ones(4, 4, dtype=torch.bfloat16)}
+    apply_contractive_gains(sd, {1: 0.5})
+    assert (sd["blocks.1.mlp.l3.weight"] == 0.5).all() and (sd["blocks.1.mlp.l1.weight"] == 1).all()

@@ -9,21 +9,10 @@ from evo_amd import _build
 
 P = ctypes.c_void_p; I = ctypes.c_int64
 libs = []
-import shutil, tempfile
-for arg in sys.argv[1:]:                                       # `lib.so@8`: the build with EVO_GEMM_GROUP_M=8 (read once, at the first call:
-    name, _, gm = arg.partition("@")                           # a private copy of the file gets its own static)
-    path = _build.LIBDIR / name
-    if gm:
-        tmp = tempfile.NamedTemporaryFile(suffix=".so", delete=False).name
-        shutil.copy(path, tmp); path = tmp
-    lib = ctypes.CDLL(str(path))
+for arg in sys.argv[1:]:
+    lib = ctypes.CDLL(str(_build.LIBDIR / arg))
     fn = lib.evo_linear_mfma_bf16
     fn.argtypes = [P] * 5 + [I] * 3 + [P]; fn.restype = ctypes.c_int
-    if gm:
-        os.environ["EVO_GEMM_GROUP_M"] = gm
-        z_ = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda:0")
-        assert fn(z_.data_ptr(), z_.data_ptr(), None, None, z_.clone().data_ptr(), 256, 256, 256, torch.cuda.current_stream().cuda_stream) == 0
-        torch.cuda.synchronize(); os.environ.pop("EVO_GEMM_GROUP_M")
     libs.append((arg, fn))
 dev = "cuda:0"; M = int(os.environ.get("GEMM_M", "65536"))
 st = torch.cuda.current_stream().cuda_stream
