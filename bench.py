@@ -287,13 +287,13 @@ def box_probes(ops, device, local=0):
     out["hbm_copy_bytes"] = n
     del src, dst
     sink = torch.empty(256 * 256, dtype=torch.float32, device=device)
-    iters = 60000                                        # 256 x 4 waves x 60,000 x 16 MFMAs of 16,384 flop = 1.03e15 flop: ~0.5 s at 2 PFLOP/s
+    iters = 2000000                                      # 256 x 4 waves x 2,000,000 x 16 MFMAs of 16,384 flop = 5.4e14 flop: ~0.3-0.4 s per launch
 
     def mf():
         rc = ops.lib.evo_probe_mfma_bf16(sink.data_ptr(), 256, iters, st)
         assert rc == 0, rc
     with TelemetrySampler(local) as tel:
-        ms = ev_ms(mf, 2)
+        ms = ev_ms(mf, 1)
     out["mfma_probe_tflops"] = 256 * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12
     out["mfma_probe_ms"] = ms
     out["mfma_probe_telemetry"] = tel.summary()
@@ -627,6 +627,9 @@ def main():
         "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels, "gemm_ms_per_step": gemm_ms,
         "gemm_library_launches_per_step": kernels.get("gemm", {}).get("launches_per_step", 0),
         "box": box,
+        "weights_resident_GB": model.resident_bytes() / 1e9,
+        "weights_resident_note": "the scoring model as this run used it (default: originals + norm-folded copies + operand tables); "
+                                 "`generation.weights_resident_GB` is the same model on ONE weight set (fold_norms_)",
     }
     if "library_gemm_tflops" in box and "hbm_copy_GBs" in box:
         share = min(1.0, gemm_ms / (step_stats.get("hip_event_ms_median") or ms_per_step))
@@ -805,6 +808,16 @@ def bench_generation(device, prompt=8192, new=1024):
     from evo_amd.generation import Generator
     from evo_amd.tokenizer import CharLevelTokenizer
     model = build_model("evo-1-131k-base", device)
+    # round 6: the generation leg runs on ONE weight set (StripedHyena.fold_norms_: norm scales folded into the weights in place, no derived
+    # copies) -- prefill, decode and the pool read the same 12.9 GB + 1.6 GB of operand tables
+    gb_two = None
+    try:
+        with torch.inference_mode(False):
+            model.prepare()
+            gb_two = model.resident_bytes() / 1e9
+            model.fold_norms_()
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write(f"bench.py: fold_norms_ failed ({type(e).__name__}: {e}); generation leg on the default weight copies\n")
     ids = acgt_ids(1, prompt, 777, device)[:, 1:]                    # no BOS: generate()'s default
 
     def run(g, n):
@@ -833,7 +846,9 @@ def bench_generation(device, prompt=8192, new=1024):
            "kv_read_GB_per_token_avg": 3 * (prompt + new / 2) * 2 * 4096 * 2 / 1e9,
            "hbm_frac_with_kv": (12.906e9 + 3 * (prompt + new / 2) * 2 * 4096 * 2) / dec / 1e9 / HBM_PEAK_GBS,
            "top_k4_decode_ms_per_token": dec4 * 1e3,
-           "graph_engaged": getattr(model, "decode_graph_replays", 0) > 0}
+           "graph_engaged": getattr(model, "decode_graph_replays", 0) > 0,
+           "weights_resident_GB": model.resident_bytes() / 1e9, "weights_resident_GB_default_two_copies": gb_two,
+           "one_weight_set": bool(getattr(model, "_norms_folded", False))}
     # ---- the semantic_design usage profile on the same 7B weights: many prompts x samples, continuous batching (evo_amd/pool.py)
     # [REF semantic_design/semantic_design.py:271-360].  Tokens/s INCLUDES the prompts' prefills; a pooled step streams the weights
     # once for all live slots, so the HBM fraction is weights x steps / time.

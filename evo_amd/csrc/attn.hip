@@ -793,7 +793,9 @@ extern "C" int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void
     a.q_sb = q_sb; a.q_st = q_st; a.q_sh = q_sh; a.k_sb = k_sb; a.k_st = k_st; a.k_sh = k_sh;
     a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
     a.H = (int)H;
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    // softmax_scale <= 0 (ABI 10): the queries are PRE-SCALED by softmax_scale * log2(e) (evo_rope_qk_bf16's q_scale): scores are exponents
+    a.prescaled = softmax_scale <= 0.f ? 1 : 0;
+    a.scale_log2 = a.prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
     a.dyn_pos = nullptr; a.part_o = nullptr; a.part_ml = nullptr; a.n_splits = 1;
     // query ranges longer than one 128-row block take the 64-rows-per-wave kernel of csrc/attn_w64.hip; EVO_AMD_ATTN_FORM = 1 keeps
     // them on the 8-wave pipelined kernel of rounds 2-4 (A/B measurements), 0 on the 128-row kernel
@@ -827,7 +829,8 @@ extern "C" int evo_attn_decode_bf16(const void* q, const void* k, const void* v,
     a.q_sb = q_sb; a.q_st = 0; a.q_sh = q_sh; a.k_sb = k_sb; a.k_st = k_st; a.k_sh = k_sh;
     a.v_sb = v_sb; a.v_st = v_st; a.v_sh = v_sh;
     a.H = (int)H;
-    a.scale_log2 = softmax_scale * 1.4426950408889634f;
+    a.prescaled = softmax_scale <= 0.f ? 1 : 0;
+    a.scale_log2 = a.prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
     a.n_qblocks = 1; a.q_pad = 0; a.vt = nullptr; a.vt_row = 0;
     a.dyn_pos = dyn_pos; a.part_o = part_o; a.part_ml = part_ml; a.n_splits = (int)n_splits; a.nbh = (int)(B * H);
     hipStream_t s = (hipStream_t)stream;

@@ -16,7 +16,8 @@ struct AttnArgs {
     int64_t Tq, Tk, q_pos0;
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh;
     int H;
-    float scale_log2;      // softmax_scale * log2(e)
+    float scale_log2;      // softmax_scale * log2(e); 1 when `prescaled`
+    int prescaled;         // the queries carry softmax_scale * log2(e) already (evo_rope_qk_bf16's q_scale): scores are exponents (log2 domain)
     int n_qblocks;
     // decode (split-K) mode only
     const int64_t* dyn_pos;   // device int64 [B]: position of each row's (single) query; overrides Tk / q_pos0 when non-null

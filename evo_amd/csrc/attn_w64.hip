@@ -64,6 +64,9 @@
 #ifndef W_THR
 #define W_THR 32.0f                         // deferred-max threshold, log2 units (0 = move the reference on every new maximum)
 #endif
+#ifndef W_THRP
+#define W_THRP 64.0f                        // PRE (pre-scaled queries): a row's reference point leaves 0 only beyond +-W_THRP log2 units
+#endif
 #ifndef W_VD
 #define W_VD 4                              // V^T fragments read ahead of their MFMAs (5+: the register file spills into AGPR copies)
 #endif
@@ -107,6 +110,8 @@ __device__ __forceinline__ float w_xor32_add(float v) {
 //     explicit wait states (masking / rescale / epilogue paths).
 #define W_MFMA_S0(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(S) : "a"(KF), "a"(QF))
 #define W_MFMA_S(S, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S) : "a"(KF), "a"(QF))
+// the LAST k-step of a score tuple: D != C -- the sum accumulated in the work tuple WK lands in the exponent tuple E (a free copy)
+#define W_MFMA_SD(E, WK, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %1" : "=v"(E) : "v"(WK), "a"(KF), "a"(QF))
 #define W_MFMA_L(L, ONES, PF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(L) : "v"(ONES), "v"(PF))
 #define W_DSR_K(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF))
 #ifdef W_V_AGPR             /* experiment: V^T fragments in AGPRs too */
@@ -181,6 +186,17 @@ __device__ __forceinline__ void w_static_for_impl(F&& f, std::integer_sequence<i
 template <int N, class F>
 __device__ __forceinline__ void w_static_for(F&& f) { w_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Round 6.  (1) The score tile of the next tile is accumulated in a WORK tuple per query block (reused by both 32-key halves) and the LAST
+// QK^T MFMA of a tuple writes its result into the exponent tuple S[x][kt] (v_mfma with D != C): by then the exp stream has consumed that
+// tuple's previous contents (tile t's exponents of half kt are read in gaps 16 kt .. 16 kt + 14, the deposits sit in gaps 16 kt + 14 / 15), so
+// ONE exponent set serves both tiles -- 96 registers where S + ev took 128, and the exponents are formed IN PLACE.
+// (2) PRE: the queries arrive PRE-SCALED by softmax_scale * log2(e) (the rotary kernel folds the factor into its one rounding of q), so a
+// score IS an exponent: the 64 `fma(S, c, -m)` of a trip disappear (VALU per MFMA 5.7 -> 4.8).  The exponents are taken relative to a
+// per-row reference point that STARTS AT 0 and only moves when a tile's largest exponent leaves +-W_THRP log2 units (a row's first visible
+// tile may also move it down): P = 2^s up to 2^64, l <= 2^81, |O| <= 2^91 at T = 131,073 -- fp32 / bf16 carry the exponent, every rounding is
+// relative.  While no row of the wave has moved nothing is subtracted at all; once one has (wave-uniform `any_nm`) the tile's scores get
+// their row's offset in a burst between the two phases, like the masking of a diagonal tile.
+template <bool PRE>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[W_LDS];
 
@@ -343,8 +359,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     bool resc = false;                            // wave-uniform: some row of the wave moved its reference point for the pending tile
     const float c_sc = a.scale_log2;
 
-    f32x16_t S[2][2];                             // score tile of the NEXT tile [query block][32-key half]: VGPRs, MFMA outputs only
-    float ev[2][32];                              // its exponents s c - reference, then (next trip) the current tile's: [x][16 kt + r]
+    f32x16_t WK[2];                               // QK^T accumulation of the tuple in progress [query block]: VGPRs, MFMA operands only
+    f32x16_t S[2][2];                             // exponent tuples [query block][32-key half]: written by a tuple's last QK^T MFMA (raw scores of the
+                                                  // NEXT tile), turned into s c - reference in place by the side stream, read by the next trip's exp stream
+#define W_EL(X, I) S[X][(I) >> 4][(I) & 15]
     uint32_t pk[2][16];                           // bf16-packed P^T of the current tile [query block][4 * (16-key group) + word]
     w_u32x4 kf[4];                                // K fragments: a ring of four (see w_p1_ops): AGPRs
 
@@ -359,9 +377,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         const int g = u >> 3, x = (u >> 2) & 1, w = u & 3;
         const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;                     // index into ev[x]: 16 kt + register of the MFMA tile
 #ifdef W_ABL_EXPMUL
-        if (o < 4) { tp[o] = ev[x][r + (o & 1)] * c_sc; W_PIN(tp[o]); }
+        if (o < 4) { tp[o] = W_EL(x, r + (o & 1)) * c_sc; W_PIN(tp[o]); }
 #else
-        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(ev[x][r + (o & 1)]); W_PIN(tp[o]); }
+        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(W_EL(x, r + (o & 1))); W_PIN(tp[o]); }
 #endif
         else { pk[x][4 * g + w] = pack_bf2(tp[2 * which], tp[2 * which + 1]); W_PIN(pk[x][4 * g + w]); }
     };
@@ -374,9 +392,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         const int g = u >> 3, x = (u >> 2) & 1, w = u & 3;
         const int r = 16 * (g >> 1) + 8 * (g & 1) + 2 * w;
 #ifdef W_ABL_EXPMUL
-        if (o < 4) { tp[o] = ev[x][r + (o & 1)] * c_sc; W_PIN(tp[o]); }
+        if (o < 4) { tp[o] = W_EL(x, r + (o & 1)) * c_sc; W_PIN(tp[o]); }
 #else
-        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(ev[x][r + (o & 1)]); W_PIN(tp[o]); }
+        if (o < 4) { tp[o] = __builtin_amdgcn_exp2f(W_EL(x, r + (o & 1))); W_PIN(tp[o]); }
 #endif
         else if (o < 8) {
             const bool first_of_row = w == 0 && g == 0;
@@ -393,15 +411,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     bool upd_any = false;
     auto fma_op = [&](const int kt, const int k) __attribute__((always_inline)) {                               // k = 0..31: x = k >> 4, r = k & 15
         const int x = k >> 4, r = k & 15;
-        ev[x][16 * kt + r] = __builtin_fmaf(S[x][kt][r], c_sc, nm[x]);
-        W_PIN(ev[x][16 * kt + r]);
+        S[x][kt][r] = __builtin_fmaf(S[x][kt][r], c_sc, nm[x]);              // (in place: the tuple's last MFMA retired >= 8 gaps ago)
+        W_PIN(S[x][kt][r]);
     };
     auto max_op = [&](const int k) __attribute__((always_inline)) {              // k = 0..31: x = k & 1 (the two chains alternate), step k >> 1
         const int x = k & 1, st = k >> 1;
-        const float* e = ev[x];
-        if (st == 0) tmx[x] = fmaxf(fmaxf(e[0], e[1]), e[2]);
-        else if (st < 15) tmx[x] = fmaxf(fmaxf(tmx[x], e[2 * st + 1]), e[2 * st + 2]);
-        else tmx[x] = fmaxf(tmx[x], e[31]);
+        if (st == 0) tmx[x] = fmaxf(fmaxf(W_EL(x, 0), W_EL(x, 1)), W_EL(x, 2));
+        else if (st < 15) tmx[x] = fmaxf(fmaxf(tmx[x], W_EL(x, 2 * st + 1)), W_EL(x, 2 * st + 2));
+        else tmx[x] = fmaxf(tmx[x], W_EL(x, 31));
         W_PIN(tmx[x]);
     };
     // the rows' reference points for tile t+1, in four steps (both query blocks side by side: two independent dependency chains per step)
@@ -411,10 +428,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         emx[0] = w_xor32_max(tmx[0]); emx[1] = w_xor32_max(tmx[1]);
         W_PIN(emx[0]); W_PIN(emx[1]);
     };
+    bool any_nm = false;                          // PRE, wave-uniform: some row of the wave has left the reference point 0
+    bool got[2] = {false, false};                 // PRE: the tile has a visible key for the row
     auto book_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            updv[x] = seen[x] ? (emx[x] > W_THR) : (emx[x] > -INFINITY);       // (a row's first visible key always sets its reference point)
+            if constexpr (PRE) {
+                // the reference stays where it is (0 from the start) while the tile's largest exponent is inside +-W_THRP; a row's FIRST
+                // visible tile may also pull it down (nothing is accumulated yet: alpha = 0 below, nothing is rescaled)
+                got[x] = emx[x] > -INFINITY;
+                updv[x] = (emx[x] > W_THRP) || (!seen[x] && got[x] && emx[x] < -W_THRP);
+            } else {
+                updv[x] = seen[x] ? (emx[x] > W_THR) : (emx[x] > -INFINITY);   // (a row's first visible key always sets its reference point)
+            }
             dl[x] = updv[x] ? emx[x] : 0.f;
         }
         W_PIN(dl[0]); W_PIN(dl[1]);
@@ -428,18 +454,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         W_PIN(alpha[0]); W_PIN(alpha[1]); W_PIN(nm[0]); W_PIN(nm[1]);
     };
     auto book_d = [&]() __attribute__((always_inline)) {
-        seen[0] = seen[0] || updv[0]; seen[1] = seen[1] || updv[1];
+        if constexpr (PRE) { seen[0] = seen[0] || got[0]; seen[1] = seen[1] || got[1]; }
+        else { seen[0] = seen[0] || updv[0]; seen[1] = seen[1] || updv[1]; }
         upd_any = __any(updv[0] || updv[1]);
         resc = upd_any;
+        if constexpr (PRE) any_nm = any_nm || upd_any;
     };
     // side work of P.V gap j: 120 instructions spread at <= 4 per gap; the second-half score tuples (last written by the MFMAs of
     // phase-1 gaps 30 / 31) are first read in gap 8
     auto side = [&](const int j) __attribute__((always_inline)) {
         // (no loops here: a loop that contains a pin is unrolled too late for the register promotion of S / ev)
-        if (j < 8) {                                // exponents of the first-half tuples (written >= 16 MFMAs ago)
-            fma_op(0, 4 * j); fma_op(0, 4 * j + 1); fma_op(0, 4 * j + 2); fma_op(0, 4 * j + 3);
+        if (j < 8) {                                // exponents of the first-half tuples (written >= 16 MFMAs ago); PRE: the scores ARE the exponents
+            if constexpr (!PRE) { fma_op(0, 4 * j); fma_op(0, 4 * j + 1); fma_op(0, 4 * j + 2); fma_op(0, 4 * j + 3); }
         } else if (j < 16) {                        // ... of the second-half tuples
-            fma_op(1, 4 * (j - 8)); fma_op(1, 4 * (j - 8) + 1); fma_op(1, 4 * (j - 8) + 2); fma_op(1, 4 * (j - 8) + 3);
+            if constexpr (!PRE) { fma_op(1, 4 * (j - 8)); fma_op(1, 4 * (j - 8) + 1); fma_op(1, 4 * (j - 8) + 2); fma_op(1, 4 * (j - 8) + 3); }
         } else if (j < 24) {                        // row max: 16 steps per query block
             max_op(4 * (j - 16)); max_op(4 * (j - 16) + 1); max_op(4 * (j - 16) + 2); max_op(4 * (j - 16) + 3);
         } else if (j == 24) { book_a();
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) ev[x][r] -= dl[x];
+                    for (int r = 0; r < 32; ++r) W_EL(x, r) -= dl[x];
             }
         }
     };
@@ -470,6 +498,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[x][kt][r] = (32 * kt + 16 * (r >> 3) + (r & 7)) <= lim ? S[x][kt][r] : -INFINITY;
         }
+    };
+    auto add_nm = [&]() __attribute__((always_inline)) {                        // PRE, rare: rows that left the reference point 0 get their offset
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) W_EL(x, r) += nm[x];
     };
     // a tile needs masking from the first one that reaches past the wave's first row (k0 + 63 > wpos0) or past the last key (k0 + 64 > Tk)
     const int mask_from = (int)((wpos0 + 1) / KB) < n_full ? (int)((wpos0 + 1) / KB) : n_full;
@@ -501,10 +535,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             W_DSR_K(kf[f & 3], kb, (f >> 3) * (32 * W_KROW) + (f & 7) * 32); });                                                      \
         W_LGKM(0);                                                                                                                    \
         w_static_for<4>([&](auto jc) __attribute__((always_inline)) {                                                                 \
-            W_USE3(kf, qf, S);                                                                                                        \
+            W_USE3(kf, qf, S); (void)WK;                                                                                              \
             constexpr int f = (F0) + decltype(jc)::v, kt = f >> 3, ks = f & 7;                                                        \
-            if (ks == 0) { W_MFMA_S0(S[0][kt], kf[f & 3], qf[0][ks]); W_MFMA_S0(S[1][kt], kf[f & 3], qf[1][ks]); }                    \
-            else { W_MFMA_S(S[0][kt], kf[f & 3], qf[0][ks]); W_MFMA_S(S[1][kt], kf[f & 3], qf[1][ks]); }                              \
+            if (ks == 0) { W_MFMA_S0(WK[0], kf[f & 3], qf[0][ks]); W_MFMA_S0(WK[1], kf[f & 3], qf[1][ks]); }                          \
+            else if (ks < 7) { W_MFMA_S(WK[0], kf[f & 3], qf[0][ks]); W_MFMA_S(WK[1], kf[f & 3], qf[1][ks]); }                        \
+            else { W_MFMA_SD(S[0][kt], WK[0], kf[f & 3], qf[0][ks]); W_MFMA_SD(S[1][kt], WK[1], kf[f & 3], qf[1][ks]); }              \
         });
         W_PRO_BATCH(0) W_PRO_BATCH(4) W_PRO_BATCH(8) W_PRO_BATCH(12)
         W_NOP24();                                         // MFMA results -> the VALU below
@@ -560,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | DMA pieces | first V^T fragments } ---
         w_u32x4 vfr[W_VD + 1] = {};                        // V^T fragments in flight (fragment p = (16-key group p >> 2, d tile p & 3))
         w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
-            W_USE3(kf, qf, S); W_USE3(kb, vfr, vb); W_USE2(ev, pk); W_USE3(dk_off, dv_off, pc_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
+            W_USE3(kf, qf, S); W_USE3(kb, vfr, vb); W_USE2(WK, pk); W_USE3(dk_off, dv_off, pc_off); W_USE3(ksrd, vsrd, kslot); W_USE2(vslot, dv_soff);
             constexpr int i = decltype(ic)::v;
             constexpr int kt = i >> 4, ks = (i >> 1) & 7, x = i & 1;
             constexpr bool dma = (i % 3) == 1 && i < 27;   // gaps 1, 4, ..., 25 -> pieces 0..8 (0-4: K, 5-8: V; K piece 4 exists in wave 0 only)
@@ -574,7 +609,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #endif
             constexpr int f = i >> 1;                     // K fragment of this MFMA
             if (f >= 4 && x == 0) W_T_LGKM(w_wait_k1(f));
-            if (ks == 0) W_MFMA_S0(S[x][kt], kf[f & 3], qf[x][ks]); else W_MFMA_S(S[x][kt], kf[f & 3], qf[x][ks]);
+            if (ks == 0) W_MFMA_S0(WK[x], kf[f & 3], qf[x][ks]);
+            else if (ks < 7) W_MFMA_S(WK[x], kf[f & 3], qf[x][ks]);
+            else W_MFMA_SD(S[x][kt], WK[x], kf[f & 3], qf[x][ks]);   // deposit: tile t's exponents of half kt were last read in gap 16 kt + 14
             if (x == 1 && f + 4 < 16) W_T_DSR_K(kf[f & 3], kb, ((f + 4) >> 3) * (32 * W_KROW) + ((f + 4) & 7) * 32);
             if (i >= 32 - 2 * W_VD && (i & 1) == 0) {     // the first W_VD V^T fragments of P.V(tile)
                 constexpr int p = (i - (32 - 2 * W_VD)) >> 1;
@@ -606,9 +643,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
 #endif
-        if (mask_nxt) {
+        if (mask_nxt || (PRE && any_nm)) {                 // rare: the diagonal / ragged tile's mask; PRE: rows that left the reference point 0
             W_NOP24();
-            mask_tile(tile + 1);
+            if (mask_nxt) mask_tile(tile + 1);
+            if constexpr (PRE) { if (any_nm) add_nm(); }
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -618,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         w_srd_t ksrd_n = ksrd, vsrd_n = vsrd;
         bool mask_nxt_n = false;
         w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
-            W_USE3(kf, oacc, kb2); W_USE3(vb, vfr, pk); W_USE2(S, ev); W_USE2(lacc, ones);
+            W_USE3(kf, oacc, kb2); W_USE3(vb, vfr, pk); W_USE2(S, nm); W_USE2(lacc, ones);
             constexpr int j = decltype(jc)::v;
             constexpr int p = j >> 1, x = j & 1;
             constexpr int g = p >> 2, dt = p & 3;
@@ -742,6 +780,7 @@ int evo_attn_w64_launch(AttnArgs a, int64_t B, void* vt_ws, void* stream) {
     if (n_wg > 0x7fffffff || a.vt_row / KB > 0x7fffffff || DH * a.vt_row * 2 > 0xffffffffll) return -1;
     hipLaunchKernelGGL(attn_vt_kernel, dim3((unsigned)(a.vt_row / KB), (unsigned)a.H, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                        a.v, (uint16_t*)vt_ws, a.Tk, a.v_sb, a.v_st, a.v_sh, a.vt_row, a.H);
-    hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.prescaled) hipLaunchKernelGGL(attn_fwd_w64_kernel<true>, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_w64_kernel<false>, dim3((unsigned)n_wg), dim3(256), 0, (hipStream_t)stream, a);
     return evo_launch_status();
 }

@@ -236,7 +236,7 @@ extern "C" int evo_rms_finalize_f32(const float* sumsq, int64_t n_strips, int64_
 // launch at 8 x 8,193; same expression, same bits).
 __global__ __launch_bounds__(256) void rope_kernel(uint4* __restrict__ qkv, const float4* __restrict__ cos_t,
                                                    const float4* __restrict__ sin_t, int64_t n_tok, int64_t T, int H,
-                                                   int hd) {
+                                                   int hd, float q_scale) {
     const int half_vec = hd / 16;                 // 16-byte vectors per half row
     const int per_tok = 2 * H * half_vec;         // (q | k) x heads x vectors of the first half
     const int row_vecs = hd / 8;
@@ -260,10 +260,13 @@ __global__ __launch_bounds__(256) void rope_kernel(uint4* __restrict__ qkv, cons
             co[0] = c0.x; co[1] = c0.y; co[2] = c0.z; co[3] = c0.w; co[4] = c1.x; co[5] = c1.y; co[6] = c1.z; co[7] = c1.w;
             si[0] = s0.x; si[1] = s0.y; si[2] = s0.z; si[3] = s0.w; si[4] = s1.x; si[5] = s1.y; si[6] = s1.z; si[7] = s1.w;
             float o0[8], o1[8];
+            // q rows (hw < H) may carry the attention's softmax_scale * log2(e) (q_scale: folded into the ONE rounding of the rotated
+            // value, so that a score is an exponent and csrc/attn_w64.hip's PRE form needs no per-score multiply); 1 = plain rotary, exact
+            const float qs = hw < H ? q_scale : 1.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                o0[e] = x0[e] * co[e] - x1[e] * si[e];
-                o1[e] = x0[e] * si[e] + x1[e] * co[e];
+                o0[e] = (x0[e] * co[e] - x1[e] * si[e]) * qs;
+                o1[e] = (x0[e] * si[e] + x1[e] * co[e]) * qs;
             }
             row[c] = pack8(o0);
             row[half_vec + c] = pack8(o1);
@@ -272,13 +275,13 @@ __global__ __launch_bounds__(256) void rope_kernel(uint4* __restrict__ qkv, cons
 }
 
 extern "C" int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t, int64_t B, int64_t T, int64_t H,
-                                int64_t hd, void* stream) {
-    if (hd % 16 != 0 || B < 0 || T < 0) return -1;
+                                int64_t hd, float q_scale, void* stream) {
+    if (hd % 16 != 0 || B < 0 || T < 0 || !(q_scale > 0.f)) return -1;
     const int64_t n_tok = B * T;
     if (n_tok * H == 0) return 0;
     const int grid = (int)(n_tok < 65536 ? n_tok : 65536);
     hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)qkv, (const float4*)cos_t,
-                       (const float4*)sin_t, n_tok, T, (int)H, (int)hd);
+                       (const float4*)sin_t, n_tok, T, (int)H, (int)hd, q_scale);
     return evo_launch_status();
 }
 
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void rope_append_decode_kernel(uint4* __restri
                                                                  const int64_t* __restrict__ pos,
                                                                  const float* __restrict__ inv_freq, float scaling, int B,
                                                                  int H, int hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw,
-                                                                 int64_t kv_sh) {   // kv strides in 16-byte vectors
+                                                                 int64_t kv_sh, float q_scale) {   // kv strides in 16-byte vectors
     const int half_vec = hd / 16;
     const int total = B * H * half_vec;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -317,10 +320,11 @@ __global__ __launch_bounds__(256) void rope_append_decode_kernel(uint4* __restri
         float x0[8], x1[8], o0[8], o1[8];
         unpack8(qkv[row_vec + c], x0);
         unpack8(qkv[row_vec + half_vec + c], x1);
+        const float qs = which == 0 ? q_scale : 1.0f;         // (see rope_kernel)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            o0[e] = x0[e] * co[e] - x1[e] * si[e];
-            o1[e] = x0[e] * si[e] + x1[e] * co[e];
+            o0[e] = (x0[e] * co[e] - x1[e] * si[e]) * qs;
+            o1[e] = (x0[e] * si[e] + x1[e] * co[e]) * qs;
         }
         const uint4 r0 = pack8(o0), r1 = pack8(o1);
         qkv[row_vec + c] = r0;
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(256) void rope_append_decode_kernel(uint4* __restri
 
 extern "C" int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const float* inv_freq, float scaling,
                                            int64_t B, int64_t H, int64_t hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw,
-                                           int64_t kv_sh, void* stream) {
-    if (B <= 0 || H <= 0 || hd <= 0 || hd % 16 != 0 || !qkv || !kv || !pos || !inv_freq || scaling <= 0.f) return -1;
+                                           int64_t kv_sh, float q_scale, void* stream) {
+    if (B <= 0 || H <= 0 || hd <= 0 || hd % 16 != 0 || !qkv || !kv || !pos || !inv_freq || scaling <= 0.f || !(q_scale > 0.f)) return -1;
     if ((kv_sb % 8) || (kv_st % 8) || (kv_sw % 8) || (kv_sh % 8) || B * H * (hd / 16) > 0x7fffffff) return -1;
     const int total = (int)(B * H * (hd / 16));
     hipLaunchKernelGGL(rope_append_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (uint4*)qkv, (uint4*)kv, pos, inv_freq, scaling, (int)B, (int)H, (int)hd, kv_sb / 8, kv_st / 8, kv_sw / 8,
-                       kv_sh / 8);
+                       kv_sh / 8, q_scale);
     return evo_launch_status();
 }
 

@@ -349,6 +349,12 @@ static_assert(!GE_FULL || GE_ORDER == 1, "GE_FULL pairs the strips of GE_ORDER 1
 #ifndef GR_MIDB
 #define GR_MIDB 1                            // 1: the stage barrier behind the first MFMA of half 1; 0: in front of it
 #endif
+#ifndef GR_PAD
+#define GR_PAD 0
+#endif
+#ifndef GR_ALIGN
+#define GR_ALIGN 0
+#endif
 #ifndef GR_PROFILE
 #define GR_PROFILE 0                         // 1: wave 0 of workgroup 0 accumulates cycles per loop segment, written over y (tools/gemm_stage_profile.py)
 #endif
@@ -642,6 +648,14 @@ __global__ __launch_bounds__(256, 1) void gemmr_bf16_kernel(GemmArgs a) {
     //        half 1 (k 32..63)  64 MFMAs + the first fragment reads of stage g+1 + DMA W(g+2) -> slot sl (held X(g))
     uint32_t xo = 0, wo = G_SLAB, nxo = 2 * G_SLAB, nwo = 3 * G_SLAB, fxo = 4 * G_SLAB;     // slot byte offsets of stage g: X, W; stage g+1: X, W; free
     uint32_t fxl = lds_dma + 4 * G_SLAB, fwl = lds_dma, r_t0 = 0, r_t1 = 0;
+    // code-placement knobs (measurement builds; MI355X_MICROARCH.md "code-placement sensitivity of hand-written streams"): GR_PAD shifts the
+    // whole stage stream by 4-byte s_nop's, GR_ALIGN pins the head of the tile loop to a 2^GR_ALIGN-byte boundary
+#if GR_PAD
+    asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(GR_PAD));
+#endif
+#if GR_ALIGN
+    asm volatile(".p2align %0" :: "n"(GR_ALIGN));
+#endif
     for (int c_i = 0; c_i < n_my; ++c_i) {
 #define GR_KSTEP()                                                                                            \
         {                                                                                                     \

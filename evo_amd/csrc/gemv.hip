@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void gemv_norm_hyena_kernel(
 template <int M, bool NORM, bool STAGE>
 __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ scale,
                                                         const uint4* __restrict__ w, uint16_t* __restrict__ a, int I,
-                                                        int nvec, float eps, float inv_sqrt_d) {
+                                                        int nvec, float eps, float inv_sqrt_d, int grouped) {
     constexpr int GV_R = 4;                                  // rows per wave: (n, n+1) of W1 and of W2
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -522,7 +522,10 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int64_t n = n0 + (r & 1) < I ? n0 + (r & 1) : I - 1;
-        wrow[r] = w + ((r >> 1) * (int64_t)I + n) * nvec;
+        // plain [W1; W2]: row (r >> 1) I + n.  grouped (HipOps.pack_gate_weights: blocks of [32 rows of W1 | the same 32 rows of W2], the
+        // order the gated MFMA launch reads -- ONE copy of l1 | l2 serves prefill and decode): row 64 (n / 32) + 32 (r >> 1) + n % 32
+        const int64_t row = grouped ? 64 * (n >> 5) + 32 * (r >> 1) + (n & 31) : (r >> 1) * (int64_t)I + n;
+        wrow[r] = w + row * nvec;
     }
     // (STAGE) the staging wave's x / scale requests go out first, so they come back first
     uint4 st_x[8], st_s[8];
@@ -791,8 +794,10 @@ extern "C" int evo_hyena_decode_fused_small_m(const void* x, const void* norm_sc
 }
 
 static int mlp_gate_launch(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
-                           float eps, hipStream_t s) {
+                           float eps, int64_t grouped, hipStream_t s) {
     if (M < 1 || M > 8 || I <= 0 || I % 2 != 0 || K <= 0 || K % 8 != 0 || I > 0x3fffffff) return -1;
+    if (grouped && I % 32 != 0) return -1;
+    const int grp = grouped ? 1 : 0;
     if (M > 4 && !(scale && K == 4096)) return -1;           // batches of 5-8 rows exist in the LDS-staged form only
     const dim3 grid((unsigned)((I / 2 + 3) / 4)), block(256);
     const float isd = 1.0f / sqrtf((float)K);
@@ -801,16 +806,16 @@ static int mlp_gate_launch(const void* x, const void* scale, const void* w12, vo
 #define EVO_MG(MM)                                                                                            \
     if (scale && stage)                                                                                       \
         hipLaunchKernelGGL((gemv_gate_kernel<MM, true, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
-                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd);                  \
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd, grp);             \
     else if (scale)                                                                                           \
         hipLaunchKernelGGL((gemv_gate_kernel<MM, true, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)scale, \
-                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd);                  \
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd, grp);             \
     else                                                                                                      \
         hipLaunchKernelGGL((gemv_gate_kernel<MM, false, false>), grid, block, 0, s, (const uint4*)x, (const uint4*)nullptr, \
-                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), 0.f, 0.f)
+                           (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), 0.f, 0.f, grp)
 #define EVO_MGS(MM)                                                                                           \
     hipLaunchKernelGGL((gemv_gate_kernel<MM, true, true>), grid, block, lds, s, (const uint4*)x, (const uint4*)scale, \
-                       (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd)
+                       (const uint4*)w12, (uint16_t*)a, (int)I, (int)(K / 8), eps, isd, grp)
     switch (M) {
         case 1: EVO_MG(1); break;
         case 2: EVO_MG(2); break;
@@ -827,14 +832,14 @@ static int mlp_gate_launch(const void* x, const void* scale, const void* w12, vo
 }
 
 extern "C" int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
-                                         void* stream) {
-    return mlp_gate_launch(x, nullptr, w12, a, M, I, K, 0.f, (hipStream_t)stream);
+                                         int64_t grouped, void* stream) {
+    return mlp_gate_launch(x, nullptr, w12, a, M, I, K, 0.f, grouped, (hipStream_t)stream);
 }
 
 extern "C" int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, const void* w12, void* a, int64_t M,
-                                              int64_t I, int64_t K, float eps, void* stream) {
+                                              int64_t I, int64_t K, float eps, int64_t grouped, void* stream) {
     if (!scale) return -1;
-    return mlp_gate_launch(x, scale, w12, a, M, I, K, eps, (hipStream_t)stream);
+    return mlp_gate_launch(x, scale, w12, a, M, I, K, eps, grouped, (hipStream_t)stream);
 }
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,

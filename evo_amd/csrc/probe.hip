@@ -9,19 +9,25 @@
 
 typedef uint32_t p_u32x4 __attribute__((ext_vector_type(4)));
 
+// one workgroup = one contiguous 16 KiB piece (256 lanes x 4 x 16 B): four loads in flight per lane, then four stores; one piece per
+// workgroup and a grid of n / 16 KiB workgroups (the dispatcher balances the channels; a 4,096-workgroup grid-stride loop measured 4.6 TB/s)
 __global__ __launch_bounds__(256) void probe_copy_kernel(const p_u32x4* __restrict__ src, p_u32x4* __restrict__ dst, int64_t n16) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const p_u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (base + 768 < n16) {
+        const p_u32x4 a = __builtin_nontemporal_load(src + base), b = __builtin_nontemporal_load(src + base + 256),
+                      c = __builtin_nontemporal_load(src + base + 512), d = __builtin_nontemporal_load(src + base + 768);
+        __builtin_nontemporal_store(a, dst + base); __builtin_nontemporal_store(b, dst + base + 256);
+        __builtin_nontemporal_store(c, dst + base + 512); __builtin_nontemporal_store(d, dst + base + 768);
+    } else {
+        for (int64_t i = base; i < n16; i += 256) dst[i] = src[i];
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 extern "C" int evo_probe_copy_f4(const void* src, void* dst, int64_t nbytes, void* stream) {
     if (!src || !dst || nbytes <= 0 || nbytes % 16 != 0) return -1;
-    hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const p_u32x4*)src, (p_u32x4*)dst, nbytes / 16);
+    const int64_t n16 = nbytes / 16, blocks = (n16 + 1023) / 1024;
+    if (blocks > 0x7fffffff) return -1;
+    hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const p_u32x4*)src, (p_u32x4*)dst, n16);
     return evo_launch_status();
 }
 
@@ -49,14 +55,20 @@ __global__ __launch_bounds__(256, 1) void probe_mfma_kernel(float* out, int iter
         }
     f32x4_t acc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i])); }
+    asm volatile("s_nop 7" ::: "memory");
     for (int it = 0; it < iters; ++it) {
+        // accumulators pinned to AGPRs by inline asm (as a builtin hipcc shuffles them through overlapping register tuples); one s_nop per
+        // MFMA: back-to-back 4-pass MFMAs of one wave issue every 28 clocks, with any instruction between them every 16-18
+        // (profiles/r02_gemm_notes.txt).  An accumulator is touched once per 16 MFMAs: no hazard to pad.
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i & 3]), __builtin_bit_cast(bf16x8_t, fb[i >> 2]), acc[i], 0, 0, 0);
-        // keep the accumulators bounded and the operands moving: the sign pattern of one A fragment flips every trip (one VALU op per 16 MFMAs)
-        fa[it & 3][0] ^= 0x80008000u;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 0" : "+a"(acc[i]) : "v"(fa[i & 3]), "v"(fb[i >> 2]));
+        // keep the operands moving: the sign pattern of one A fragment word flips every trip (one VALU op per 16 MFMAs)
+        fa[0][0] ^= 0x80008000u;
+        asm volatile("" : "+v"(fa[0]));
     }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];

@@ -66,6 +66,58 @@ def blocked_constants(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.
     return {"T0": _split_bf16(T0, 2), "W": _split_bf16(W, 3), "G": G.float(), "Gs": _split_bf16(G, 2), "P": P.float(), "h": h}
 
 
+# ---- what the bf16 hi / lo operands can hold -------------------------------------------------------------------------------------------
+# The carry product  yc[i] = sum_m G[i][m] S_start[m]  runs mode by mode on bf16 hi + lo splits of G and of the fp32 block states (each
+# 2^-17 relative), and the block states themselves come out of bf16-split aggregates (2^-17 again).  That is ample while the modes'
+# contributions |G| |S| are of the size of their sum -- the synthetic law of the bench, upstream's init, every "plain" regime of
+# tests/test_gpu_parity_r6.py.  A filter whose modes CANCEL (large residues of opposite sign on nearly equal poles: the sum is a small
+# difference of large terms) amplifies the per-mode 2^-16 by the cancellation factor; at 1 % cancellation the error before the output
+# rounding reaches 1e-3 of the channel's output scale (measured, CPU emulation and MI355X) -- the size of a bf16 rounding.  Real
+# checkpoints keep poles / residues in fp32 for a reason [REF evo/models.py:146-148], so this is decided per layer when its table is
+# built: table_precision() predicts, from the filter alone, the carry term's split error against the output's scale under a unit-variance
+# white input; a layer with any channel above TABLE_TOL is routed to the modal kernels (csrc/hyena.hip: fp32 states, no split), which hold
+# every regime (tests/test_gpu_parity_r6.py proves both the bound and that the guard fires).
+TABLE_TOL = 5.0e-4       # (at 1e-3 a channel sits 1.2e-4 of its scale outside the bf16 bound on MI355X: tests/test_gpu_parity_r6.py)
+T_CAP = 131072.0          # longest context the variance bounds are taken over (|p| = 1 states grow like sqrt(T))
+
+
+def table_precision(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.Tensor = None) -> torch.Tensor:
+    """[D] fp64: predicted (split error of the carry product) / (output scale) per channel.
+         error_i  = 2^-16 sqrt( sum_s |R_s p_s^(i+1)|^2 V_s ),  V_s = min(1 / (1 - |p_s|^2), T_CAP)   (state variance per unit input variance)
+         scale    = sqrt( sum_k h_k^2 + D^2 )                   (closed form over mode pairs, |1 / (1 - q)| capped at T_CAP; at least the
+                                                                  energy of the first L taps, which the Toeplitz table holds exactly)
+       Over-predicts the measured rms error by ~10x (errors of different modes partly cancel) and tracks the measured worst element."""
+    D = poles.shape[0]
+    p = torch.view_as_complex(poles.double().contiguous())
+    r = torch.view_as_complex(residues.double().contiguous())
+    pw = torch.ones(D, NS, L + 1, dtype=torch.complex128, device=poles.device)
+    for i in range(1, L + 1):
+        pw[..., i] = pw[..., i - 1] * p
+    a2 = (p.abs() ** 2).clamp(max=1.0 - 1.0 / T_CAP)
+    V = 1.0 / (1.0 - a2)                                                        # [D, 8]
+    Gc = r[..., None] * pw[..., 1:L + 1]
+    err = (2.0 ** -16) * torch.sqrt(((Gc.real ** 2 + Gc.imag ** 2) * V[..., None]).sum(1)).amax(-1)
+
+    def inv_capped(q):                                                          # 1 / (1 - q), its modulus capped at T_CAP (phase kept)
+        d = 1.0 - q
+        return torch.where(d.abs() >= 1.0 / T_CAP, 1.0 / d, d.conj() / d.abs().clamp_min(1e-300) * T_CAP)
+    pp, pc = p[:, :, None] * p[:, None, :], p[:, :, None] * p[:, None, :].conj()
+    rr, rc = r[:, :, None] * r[:, None, :], r[:, :, None] * r[:, None, :].conj()
+    eye = torch.eye(NS, dtype=torch.bool, device=poles.device)[None]
+    cross = torch.where(eye, torch.zeros((), dtype=torch.complex128, device=poles.device), rc * inv_capped(pc))
+    e = 0.5 * ((rr * inv_capped(pp)).sum((1, 2)).real + cross.sum((1, 2)).real + ((r.abs() ** 2) * V).sum(1))
+    h = (r[..., None] * pw[..., :L]).real.sum(1)                                # the first L taps
+    e = torch.maximum(e, (h ** 2).sum(-1))
+    if dskip is not None:
+        e = e + dskip.double() ** 2
+    return err / torch.sqrt(e).clamp_min(1e-300)
+
+
+def table_ok(poles: torch.Tensor, residues: torch.Tensor, dskip: torch.Tensor = None, tol: float = TABLE_TOL) -> bool:
+    """True when every channel's predicted split error stays below `tol` of its output scale: the layer may run csrc/hyena_ct.hip."""
+    return bool((table_precision(poles, residues, dskip) <= tol).all())
+
+
 # ---- MFMA operand order -------------------------------------------------------------------------------------------------
 # One table row per channel: 52 dwords per lane x 64 lanes, in the order csrc/hyena_ct.hip keeps them in registers.
 #   v_mfma_f32_16x16x32_bf16  A operand: lane l holds A[row = l & 15][k = 8 (l >> 4) + 0..7]  (4 dwords = 8 bf16)

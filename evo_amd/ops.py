@@ -32,7 +32,7 @@ _SIGNATURES = {
     "evo_hyena_carry_add": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_hyena_apply": ([_PTR] * 10 + [_I64] * 5 + [_PTR], _c.c_int),
     "evo_hyena_step": ([_PTR] * 9 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
+    "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _F32, _PTR], _c.c_int),
     "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR, _PTR], _c.c_int),
     "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
@@ -49,14 +49,14 @@ _SIGNATURES = {
     "evo_rms_finalize_f32": ([_PTR, _I64, _I64, _PTR, _I64, _I64, _I64, _F32, _PTR, _PTR], _c.c_int),
     "evo_probe_copy_f4": ([_PTR, _PTR, _I64, _PTR], _c.c_int),
     "evo_probe_mfma_bf16": ([_PTR, _I64, _I64, _PTR], _c.c_int),
-    "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_mlp_gate_small_m_bf16": ([_PTR] * 3 + [_I64] * 4 + [_PTR], _c.c_int),
     "evo_norm_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
-    "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
+    "evo_norm_mlp_gate_small_m_bf16": ([_PTR] * 4 + [_I64] * 3 + [_c.c_float, _I64, _PTR], _c.c_int),
     "evo_hyena_decode_fused_small_m": ([_PTR] * 12 + [_I64] * 3 + [_c.c_float, _PTR], _c.c_int),
     "evo_gelu_gate_bf16": ([_PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_logprob_entropy": ([_PTR, _I64, _PTR, _PTR, _PTR, _I64, _I64, _PTR], _c.c_int),
     "evo_unembed_logprob_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_rope_append_decode_bf16": ([_PTR] * 4 + [_F32] + [_I64] * 7 + [_PTR], _c.c_int),
+    "evo_rope_append_decode_bf16": ([_PTR] * 4 + [_F32] + [_I64] * 7 + [_F32, _PTR], _c.c_int),
 }
 
 _LIB = None
@@ -179,6 +179,8 @@ class HipOps:
         # round 5: the RMSNorm passes of prefill-sized batches ride in the epilogues of the dense layers around them (csrc/gemm.hip, NF;
         # False = the separate rmsnorm launches: bench.py's A/B leg, the routing test)
         self.fuse_norm = True
+        self.attn_prescale = True         # the model folds softmax_scale * log2(e) into the rotary kernel's one rounding of q; attention kernels take scores as exponents (csrc/attn_w64.hip PRE)
+        self.hyena_table_guard = True     # Hyena layers whose filter the bf16 hi / lo operand tables cannot hold run the modal kernels (hyena_tables.table_precision)
         # all_gemm_mfma = False puts the plain dense layers (l3, the unembedding of model(ids)) back on hipBLASLt through torch.addmm:
         # the library is 1-3 % faster on l3's shape (K = 11,008; profiles/r03_gemm_notes.txt) -- bench.py times that leg beside the headline
         self.all_gemm_mfma = True
@@ -677,14 +679,14 @@ class HipOps:
         """mlp_gate(rmsnorm(x) * scale, w12) with the norm as a row factor in the gated dense layer's epilogue (see linear_rs);
         w12g_folded = pack_gate_weights(fold_norm_scale(w12, scale))."""
         M, K = x.shape
-        I = w12.shape[0] // 2
+        I = w12g_folded.shape[0] // 2
         Mm = self._nf_main_rows(M)
         a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
         with self._t("gemm_gate"):
             _check(self.lib.evo_mlp_gate_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w12g_folded.data_ptr(), a.data_ptr(), Mm, I, K, _stream()),
                    "evo_mlp_gate_mfma_nf_bf16")
         if M > Mm:
-            a[Mm:] = self.mlp_gate(x[Mm:], w12, scale, eps)
+            a[Mm:] = self.mlp_gate(x[Mm:], w12, scale, eps, w12g=None if w12 is not None else w12g_folded)
         return a
 
     def zt_stream_rows_ok(self, B: int, T: int) -> bool:
@@ -796,19 +798,25 @@ class HipOps:
                 dskip.data_ptr(), y.data_ptr(), M, D, n_heads, float(eps), _stream()), "evo_hyena_decode_fused_small_m")
         return y
 
-    def rope_(self, qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
-        """In-place NeoX rotary on the q and k thirds of qkv [B,T,3,H,hd]."""
+    @staticmethod
+    def attn_q_scale(hd: int) -> float:
+        """softmax_scale * log2(e) for head dim hd: what `rope_(..., q_scale=)` folds into the queries when the attention runs `prescaled`."""
+        return (1.0 / math.sqrt(hd)) * 1.4426950408889634
+
+    def rope_(self, qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q_scale: float = 1.0) -> torch.Tensor:
+        """In-place NeoX rotary on the q and k thirds of qkv [B,T,3,H,hd].  `q_scale`: the rotated queries are multiplied by it before their
+        one rounding (attn_q_scale(hd) when the attention that follows is called with prescaled=True; 1.0: plain rotary, exact)."""
         self._need(qkv, torch.bfloat16, "rope qkv")
         self._need(cos, torch.float32, "rope cos")
         self._need(sin, torch.float32, "rope sin")
         B, T, three, H, hd = qkv.shape
         assert three == 3 and cos.shape == (T, hd // 2)
-        _check(self.lib.evo_rope_qk_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, T, H, hd, _stream()),
+        _check(self.lib.evo_rope_qk_bf16(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, T, H, hd, float(q_scale), _stream()),
                "evo_rope_qk_bf16")
         return qkv
 
     def rope_append_decode(self, qkv: torch.Tensor, kv: torch.Tensor, pos: torch.Tensor, inv_freq: torch.Tensor,
-                           scaling: float) -> None:
+                           scaling: float, q_scale: float = 1.0) -> None:
         """One decode token per stream: NeoX rotary on q and k of qkv [B,1,3,H,hd] (in place) at position pos[b] (/ scaling) and
         kv[b, pos[b]] = (k, v) -- kv [>=B, cap, 2, H, hd].  One launch; bit-identical to the rotary table + rope_ + indexed copy."""
         self._need(qkv, torch.bfloat16, "rope_append_decode qkv")
@@ -820,10 +828,11 @@ class HipOps:
         self._need(inv_freq, torch.float32, "rope_append_decode inv_freq")
         _check(self.lib.evo_rope_append_decode_bf16(qkv.data_ptr(), kv.data_ptr(), pos.data_ptr(), inv_freq.data_ptr(),
                                                     float(scaling), B, H, hd, kv.stride(0), kv.stride(1), kv.stride(2),
-                                                    kv.stride(3), _stream()), "evo_rope_append_decode_bf16")
+                                                    kv.stride(3), float(q_scale), _stream()), "evo_rope_append_decode_bf16")
 
-    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos0: int) -> torch.Tensor:
-        """Causal attention; q [B,Tq,H,128], k/v [B,Tk,H,128] (strided views allowed, last dim dense)."""
+    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos0: int, prescaled: bool = False) -> torch.Tensor:
+        """Causal attention; q [B,Tq,H,128], k/v [B,Tk,H,128] (strided views allowed, last dim dense).  `prescaled`: q already carries
+        softmax_scale * log2(e) (rope_'s q_scale = attn_q_scale(hd)): the 64-rows-per-wave kernel then runs without its per-score multiply."""
         for t, nm in ((q, "q"), (k, "k"), (v, "v")):
             if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
                 raise RuntimeError(f"attention {nm}: need a ROCm bf16 tensor with a dense last dim")
@@ -838,11 +847,11 @@ class HipOps:
             _check(self.lib.evo_attn_fwd_causal_bf16(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tq, Tk, int(q_pos0),
                 q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                v.stride(0), v.stride(1), v.stride(2), 1.0 / math.sqrt(hd), _ptr(vt), _stream()), "evo_attn_fwd_causal_bf16")
+                v.stride(0), v.stride(1), v.stride(2), 0.0 if prescaled else 1.0 / math.sqrt(hd), _ptr(vt), _stream()), "evo_attn_fwd_causal_bf16")
         return o
 
     def attention_decode(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
-                         pos: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
+                         pos: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, prescaled: bool = False) -> torch.Tensor:
         """One query per sequence against the KV cache: q [B,1,H,128]; k/v [B,Tk,H,128] views.  With `pos`
         (device int64 [B], or [1] = same for every row) row b's query sits at pos[b] and sees keys [0,pos[b]];
         Tk is then just the capacity."""
@@ -868,7 +877,7 @@ class HipOps:
             _check(self.lib.evo_attn_decode_bf16(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Tk, q.stride(0), q.stride(2),
                 k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2), _ptr(pos),
-                part_o.data_ptr(), part_ml.data_ptr(), n_splits, 1.0 / math.sqrt(hd), _stream()),
+                part_o.data_ptr(), part_ml.data_ptr(), n_splits, 0.0 if prescaled else 1.0 / math.sqrt(hd), _stream()),
                 "evo_attn_decode_bf16")
         return o
 
@@ -907,41 +916,48 @@ class HipOps:
                 and w12g.dtype == torch.bfloat16 and x.is_contiguous() and w12g.is_contiguous()
                 and M * K * 2 < 0xffffffff and w12g.shape[0] * K * 2 < 0xffffffff)
 
-    def mlp_gate(self, x: torch.Tensor, w12: torch.Tensor, norm_scale: Optional[torch.Tensor] = None,
+    def mlp_gate(self, x: torch.Tensor, w12: Optional[torch.Tensor], norm_scale: Optional[torch.Tensor] = None,
                  eps: float = 0.0, w12g: Optional[torch.Tensor] = None) -> torch.Tensor:
         """a [M, I] = gelu(x' @ W1^T) * (x' @ W2^T), w12 = [W1; W2] ([2I, K]); x' = x, or rmsnorm(x) * norm_scale when
         `norm_scale` is given.  Decode-sized batches (M <= 4) take ONE weight-streaming launch; prefill-sized ones the
         matrix-core dense layer with the gate in its epilogue when `w12g` (pack_gate_weights(w12)) is given -- the
-        [M, 2 I] intermediate is never written; everything else is (norm,) dense layer and gate kernel."""
+        [M, 2 I] intermediate is never written; everything else is (norm,) dense layer and gate kernel.
+        `w12 = None` (round 6, one weight set: StripedHyena.fold_norms_): only the regrouped copy w12g exists -- the weight-streaming
+        launches read it in that row order (`grouped`), the unfused fallback un-groups the dense layer's columns."""
         M, K = x.shape
-        I = w12.shape[0] // 2
+        wsrc = w12 if w12 is not None else w12g
+        grouped = 1 if w12 is None else 0
+        I = wsrc.shape[0] // 2
         if self.mlp_gate_fused_ok(x, w12g):
             if norm_scale is not None:
                 x = self.rmsnorm(x, None, norm_scale, eps)
             a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
-            r = self._tail_rows(x, w12)                           # the BOS sliver (M % 256 <= 16) goes through the small-M path
+            r = self._tail_rows(x, wsrc)                          # the BOS sliver (M % 256 <= 16) goes through the small-M path
             with self._t("gemm_gate"):
                 _check(self.lib.evo_mlp_gate_mfma_bf16(x.data_ptr(), w12g.data_ptr(), a.data_ptr(), M - r, I, K, _stream()),
                        "evo_mlp_gate_mfma_bf16")
             if r:
-                a[M - r:] = self.mlp_gate(x[M - r:], w12)
+                a[M - r:] = self.mlp_gate(x[M - r:], w12, w12g=w12g if w12 is None else None)
             return a
-        if ((1 <= M <= 4 or (M <= 8 and K == 4096 and norm_scale is not None)) and x.is_cuda and x.dtype == torch.bfloat16 and w12.dtype == torch.bfloat16 and x.is_contiguous()
-                and w12.is_contiguous() and K % 8 == 0 and I % 2 == 0
+        if ((1 <= M <= 4 or (M <= 8 and K == 4096 and norm_scale is not None)) and x.is_cuda and x.dtype == torch.bfloat16 and wsrc.dtype == torch.bfloat16 and x.is_contiguous()
+                and wsrc.is_contiguous() and K % 8 == 0 and I % 2 == 0 and (not grouped or I % 32 == 0)
                 and (norm_scale is None or (norm_scale.dtype == torch.bfloat16 and norm_scale.is_contiguous()))):
             a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
             with self._t("gemv_gate"):
                 if norm_scale is None:
-                    _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), w12.data_ptr(), a.data_ptr(), M, I, K,
+                    _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), wsrc.data_ptr(), a.data_ptr(), M, I, K, grouped,
                                                               _stream()), "evo_mlp_gate_small_m_bf16")
                 else:
-                    _check(self.lib.evo_norm_mlp_gate_small_m_bf16(x.data_ptr(), norm_scale.data_ptr(), w12.data_ptr(),
-                                                                   a.data_ptr(), M, I, K, float(eps), _stream()),
+                    _check(self.lib.evo_norm_mlp_gate_small_m_bf16(x.data_ptr(), norm_scale.data_ptr(), wsrc.data_ptr(),
+                                                                   a.data_ptr(), M, I, K, float(eps), grouped, _stream()),
                            "evo_norm_mlp_gate_small_m_bf16")
             return a
         if norm_scale is not None:
             x = self.rmsnorm(x, None, norm_scale, eps)
-        return self.gelu_gate(self.linear(x, w12, None))
+        g = self.linear(x, wsrc, None)
+        if grouped:                                               # columns come out as [32 of z1 | the same 32 of z2] per block: back to [z1 | z2]
+            g = g.view(M, I // 32, 2, 32).permute(0, 2, 1, 3).reshape(M, 2 * I).contiguous()
+        return self.gelu_gate(g)
 
     def gelu_gate(self, g: torch.Tensor) -> torch.Tensor:
         self._need(g, torch.bfloat16, "gelu_gate g")

@@ -140,6 +140,8 @@ class StripedHyena(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for StripedHyena: missing keys {missing}, "
                                f"unexpected keys {unexpected}")
+        if getattr(self, "_norms_folded", False):
+            raise RuntimeError("load_state_dict on a model that holds one folded weight set (fold_norms_): build a fresh StripedHyena")
         for k, t in state_dict.items():
             if k not in own or k == "unembed.weight":
                 continue
@@ -180,6 +182,12 @@ class StripedHyena(nn.Module):
         return self._ops
 
     def _pack(self):
+        if getattr(self, "_norms_folded", False):
+            raise RuntimeError("this StripedHyena holds ONE folded weight set (fold_norms_): its derived tensors cannot be rebuilt from the "
+                               "parameters -- moving / re-typing / re-loading needs a fresh model")
+        self._pack_impl()
+
+    def _pack_impl(self):
         """Derived device-side layouts: fused [l1;l2] weight (one GEMM for the gated MLP) with the inner size
         zero-padded to a multiple of 256 (10928 -> 11008: hipBLASLt runs the l3 GEMM, K = inner, 14 % faster
         without a K tail and the fused l1|l2 GEMM 3 % faster; the padded rows/columns are exact zeros, so
@@ -219,6 +227,7 @@ class StripedHyena(nn.Module):
                 # model): built by _mfma_table on the first parallel Hyena call of the layer -- or up front by prepare() --, never for
                 # decode-only use.  The operator reads the projection weight as it is (no regrouped copy).
                 f._mfma_tab = None
+                f._tab_prec = None                              # hyena_tables.table_precision's worst channel (decided with the table: _table_ok)
         self._packed = True
 
     def prepare(self, prefill: bool = True) -> "StripedHyena":
@@ -226,14 +235,20 @@ class StripedHyena(nn.Module):
         with `prefill` the regrouped l1 | l2 copies of the one-launch gated MLP (5.8 GB at 7B) and the Hyena layers' MFMA operand tables
         (1.6 GB) that prefill-sized batches use.  A server calls it at load time: an out-of-memory condition then surfaces before any
         KV cache or activation exists, the first request does not pay the packing, and the tensors are ordinary (not inference-mode)
-        tensors whatever mode the first forward runs under.  Decode-only deployments pass prefill=False."""
+        tensors whatever mode the first forward runs under.  Decode-only deployments pass prefill=False.
+        Footprint at 7B: 12.9 GB of weights + 5.8 GB (l1 | l2 folded and regrouped) + 3.2 GB (folded projections / Wqkv) + 1.6 GB (operand
+        tables).  A batch below 1,024 rows, a padding mask or `fuse_norm = False` later adds the UNFOLDED regrouped l1 | l2 (5.8 GB) on
+        first use -- not covered by this call's out-of-memory check: `release_unused_weight_copies()` drops whichever set the current
+        routing does not read, `fold_norms_()` keeps ONE weight set for good (14.5 GB)."""
         with torch.inference_mode(False), torch.no_grad():
-            if not self._packed:
+            if not self._packed and not getattr(self, "_norms_folded", False):
                 self._pack()
             if prefill:
                 nf = getattr(self.ops, "fuse_norm", False) and hasattr(self.ops, "fold_norm_scale") and self.blocks[0].mlp._w12g_ok
                 for blk in self.blocks:
-                    if nf:                                   # the norm-folded copies the prefill launches read (see _nf_ok)
+                    if getattr(self, "_norms_folded", False):
+                        pass                                     # (one weight set: nothing to derive but the operand tables)
+                    elif nf:                                   # the norm-folded copies the prefill launches read (see _nf_ok)
                         self._folded(blk.mlp, "_w12g_f", blk.mlp._w12, blk.post_norm.scale, gate=True)
                         if isinstance(blk, _HyenaBlock):
                             self._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
@@ -241,9 +256,114 @@ class StripedHyena(nn.Module):
                             self._folded(blk.inner_mha_cls, "_wqkv_f", blk.inner_mha_cls.Wqkv.weight, blk.pre_norm.scale)
                     else:
                         self._gate_pack(blk, 1 << 20)
-                    if isinstance(blk, _HyenaBlock) and hasattr(self.ops, "hyena_ct"):
+                    if isinstance(blk, _HyenaBlock) and hasattr(self.ops, "hyena_ct") and self._table_ok(blk):
                         self._mfma_table(blk)
         return self
+
+    # ------------------------------------------------------------------ one weight set (round 6)
+    def fold_norms_(self) -> "StripedHyena":
+        """ONE resident copy of every weight: the block norms' scale vectors are folded INTO the dense layers that consume them, in place --
+        projections / Wqkv <- bf16(W diag(g_pre)), l1 | l2 <- bf16([W1; W2] diag(g_post)) kept only in the gated launch's row order, the
+        scale vectors set to 1 -- and every derived copy is dropped (the unfolded regrouped l1 | l2, the folded projection copies).  The model
+        is then the SAME function with unit norm scales (what the prefill path has computed since round 5: one rounding of the weight where
+        the reference rounds the normalised activation); the decode launches take the same tensors (their RMSNorm multiplies by 1; the
+        weight-streaming gate launches read l1 | l2 in the grouped order, include/evo_mi355x.h ABI 10).  Resident at 7B: 12.9 GB of weights +
+        1.6 GB of Hyena operand tables instead of ~23.5 GB [REF evo/models.py:146-150: the reference holds one bf16 copy of the model].
+        One-way: `state_dict()` afterwards returns the folded, unit-scale equivalent (l1 / l2 un-grouped on demand); moving the model to
+        another device / dtype or loading another state dict needs a fresh model.  A serving deployment calls
+        `model.to(device).prepare().fold_norms_()` once after loading."""
+        if getattr(self, "_norms_folded", False):
+            return self
+        from ..ops import HipOps                                 # (fold_norm_scale / pack_gate_weights are pure tensor functions)
+        ops = self.ops
+        with torch.inference_mode(False), torch.no_grad():
+            if not self._packed:
+                self._pack()
+            for blk in self.blocks:
+                mlp = blk.mlp
+                inner = mlp.l1.weight.shape[0]
+                w12f = HipOps.fold_norm_scale(mlp._w12, blk.post_norm.scale.data)
+                if mlp._w12g_ok and hasattr(ops, "pack_gate_weights"):
+                    mlp._w12g = ops.pack_gate_weights(w12f)          # the ONLY copy of l1 | l2 from here on
+                    mlp._w12 = None
+                    mlp._l12_shape = (inner, w12f.shape[1])
+                    mlp.l1.weight.data = w12f.new_empty(0)
+                    mlp.l2.weight.data = w12f.new_empty(0)
+                else:                                               # (toy dims outside the gated launch's contract: the plain order stays)
+                    ipad = w12f.shape[0] // 2
+                    mlp._w12 = w12f
+                    mlp._w12g = None
+                    mlp.l1.weight.data = w12f[:inner]
+                    mlp.l2.weight.data = w12f[ipad:ipad + inner]
+                mlp._w12g_f = None
+                del w12f
+                if isinstance(blk, _HyenaBlock):
+                    blk.projections.weight.data = HipOps.fold_norm_scale(blk.projections.weight.data, blk.pre_norm.scale.data)
+                    blk._wp_f = None
+                else:
+                    mha = blk.inner_mha_cls
+                    mha.Wqkv.weight.data = HipOps.fold_norm_scale(mha.Wqkv.weight.data, blk.pre_norm.scale.data)
+                    mha._wqkv_f = None
+                blk.pre_norm.scale.data = torch.ones_like(blk.pre_norm.scale.data)
+                blk.post_norm.scale.data = torch.ones_like(blk.post_norm.scale.data)
+            self._norms_folded = True
+            self._dgraph = None
+        return self
+
+    def release_unused_weight_copies(self) -> int:
+        """Drops the derived weight copies the CURRENT routing does not read (a long-lived server that once ran a sub-1,024-row
+        batch, a padding mask or `fuse_norm = False` holds the unfolded regrouped l1 | l2 (5.8 GB at 7B) beside the folded one that
+        prepare() built; prepare()'s out-of-memory check covers only one of the two).  With the norms folded (the default) the unfolded
+        regrouped copy goes, otherwise the folded ones; whatever is dropped is rebuilt on the next call that needs it.  Returns the bytes
+        released.  (`fold_norms_()` is the permanent form: one weight set.)"""
+        before = self.resident_bytes()
+        fold = getattr(self.ops, "fuse_norm", False)
+        for blk in self.blocks:
+            if getattr(self, "_norms_folded", False):
+                break
+            if fold and getattr(blk.mlp, "_w12g_f", None) is not None:
+                blk.mlp._w12g = None
+            if not fold:
+                blk.mlp._w12g_f = None
+                if isinstance(blk, _HyenaBlock):
+                    blk._wp_f = None
+                else:
+                    blk.inner_mha_cls._wqkv_f = None
+        return before - self.resident_bytes()
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if getattr(self, "_norms_folded", False):
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for i, blk in enumerate(self.blocks):
+                mlp = blk.mlp
+                if mlp._w12 is None:                              # l1 / l2 live in the grouped buffer only: un-group on demand (a copy)
+                    inner, K = mlp._l12_shape
+                    g = mlp._w12g.view(-1, 2, 32, K)
+                    sd[f"{prefix}blocks.{i}.mlp.l1.weight"] = g[:, 0].reshape(-1, K)[:inner]
+                    sd[f"{prefix}blocks.{i}.mlp.l2.weight"] = g[:, 1].reshape(-1, K)[:inner]
+        return sd
+
+    def resident_bytes(self) -> int:
+        """Device bytes this model holds: parameters, buffers and every derived tensor hanging off its modules (fused / regrouped / folded
+        weight copies, Hyena operand tables), each storage counted once."""
+        seen, total = set(), 0
+
+        def add(t):
+            nonlocal total
+            if isinstance(t, torch.Tensor) and t.numel():
+                st = t.untyped_storage()
+                key = (st.data_ptr(), st.nbytes())
+                if key not in seen:
+                    seen.add(key)
+                    total += st.nbytes()
+        for mod in self.modules():
+            for t in list(mod._parameters.values()) + list(mod._buffers.values()):
+                add(t)
+            for k, v in vars(mod).items():
+                if k.startswith("_") and isinstance(v, torch.Tensor):
+                    add(v)
+        return total
 
     # ------------------------------------------------------------------ caches
     def initialize_inference_params(self):
@@ -330,12 +450,15 @@ class StripedHyena(nn.Module):
         D = self.hidden_size
         if mask is not None or not getattr(ops, "fuse_norm", False) or not hasattr(ops, "nf_shape_ok"):
             return False
-        ipad = self.blocks[0].mlp._w12.shape[0] // 2
+        m0 = self.blocks[0].mlp
+        ipad = (m0._w12 if m0._w12 is not None else m0._w12g).shape[0] // 2
         return (ops.nf_shape_ok(M, D, D) and ops.nf_shape_ok(M, 3 * D, D) and ops.nf_shape_ok(M, 2 * ipad, D) and ops.nf_shape_ok(M, D, ipad)
                 and getattr(self.blocks[0].mlp, "_w12g_ok", False) and getattr(ops, "mlp_gate_fused", False))
 
     def _folded(self, owner, name: str, w: torch.Tensor, g: torch.Tensor, gate: bool = False) -> torch.Tensor:
         """bf16(W diag(g)) of a norm-consuming layer (for l1 | l2: in the gated launch's row order), built on first use / by prepare()."""
+        if getattr(self, "_norms_folded", False):            # one weight set: the parameters ARE the folded weights (fold_norms_)
+            return owner._w12g if gate else w.data
         hit = getattr(owner, name, None)
         if hit is None or hit.device != w.device:
             with torch.inference_mode(False), torch.no_grad():
@@ -363,7 +486,7 @@ class StripedHyena(nn.Module):
     def _gate_pack(self, blk, M: int):
         """The regrouped l1 | l2 weight of the one-launch gated MLP, built the first time a prefill-sized batch needs it."""
         mlp = blk.mlp
-        if mlp._w12g is None and M >= 256 and getattr(mlp, "_w12g_ok", False) and getattr(self.ops, "mlp_gate_fused", False) \
+        if mlp._w12g is None and mlp._w12 is not None and M >= 256 and getattr(mlp, "_w12g_ok", False) and getattr(self.ops, "mlp_gate_fused", False) \
                 and hasattr(self.ops, "pack_gate_weights"):
             mlp._w12g = self.ops.pack_gate_weights(mlp._w12)
         return mlp._w12g
@@ -405,6 +528,19 @@ class StripedHyena(nn.Module):
             f._mfma_tab = mfma_operand_table(f._poles, f._residues, f.D.data)
         return f._mfma_tab
 
+    def _table_ok(self, blk) -> bool:
+        """Can this layer's filter go through the bf16 hi / lo operand tables of csrc/hyena_ct.hip?  (evo_amd/hyena_tables.py: filters whose
+        modes cancel to ~1 % amplify the splits' 2^-16 to a bf16 rounding; such a layer runs the modal kernels -- fp32 states, every regime.)
+        Decided once per layer from the poles / residues alone; `ops.hyena_table_guard = False` skips the check (tests of the guard itself)."""
+        f = blk.filter
+        if not getattr(self.ops, "hyena_table_guard", True):
+            return True
+        if getattr(f, "_tab_prec", None) is None:
+            from ..hyena_tables import table_precision
+            f._tab_prec = float(table_precision(f._poles, f._residues, f.D.data).max())
+        from ..hyena_tables import TABLE_TOL
+        return f._tab_prec <= TABLE_TOL
+
     def _hyena_ct_ok(self, x2d, blk, B, T) -> bool:
         ops = self.ops
         w = blk.projections.weight
@@ -424,7 +560,7 @@ class StripedHyena(nn.Module):
             y = ops.hyena_decode_fused(x2d, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias,
                                        cache.fir_state_dict[i], cache.state_dict[i], f._fir_w, f.short_filter_bias,
                                        f._poles, f._residues, f.D, H)
-        elif mask is None and self._mfma_hyena_ok(B, T) and self._hyena_ct_ok(x2d, blk, B, T):
+        elif mask is None and self._mfma_hyena_ok(B, T) and self._hyena_ct_ok(x2d, blk, B, T) and self._table_ok(blk):
             # the whole operator in ONE pass on the matrix cores (csrc/hyena_ct.hip) -- scoring and cached prefill (carry-in state + FIR
             # history in, end state out) alike.
             # z CHANNEL-MAJOR.  The pre-norm writes its rows in z^T's position order (HipOps.zt_layout: batch
@@ -514,6 +650,11 @@ class StripedHyena(nn.Module):
         off = int(cache.seqlen_offset) if cache is not None else 0
         pos = getattr(cache, "pos_tensor", None) if cache is not None else None
         q = qkv[:, :, 0]
+        # round 6: the rotary kernel folds softmax_scale * log2(e) into its one rounding of q and the attention kernels take scores as
+        # exponents (ops.attn_prescale; csrc/attn_w64.hip PRE: no per-score multiply) -- q is never cached, so K / V and the KV cache are untouched
+        pre = bool(getattr(ops, "attn_prescale", False)) and hasattr(ops, "attn_q_scale")
+        rk = {"q_scale": ops.attn_q_scale(hd)} if pre else {}
+        ak = {"prescaled": True} if pre else {}
         if pos is not None and T == 1:
             # position-independent decode step (hipGraph replay, continuous batching): one position PER ROW, in
             # device memory.  The rotary kernel indexes its table by token, so the B rows are presented as one
@@ -521,15 +662,15 @@ class StripedHyena(nn.Module):
             kv = cache.key_value_memory_dict[i][:B]
             if hasattr(ops, "rope_append_decode") and pos.numel() == B:
                 # rotary at each row's position + the KV append in one launch (no per-step cos / sin table)
-                ops.rope_append_decode(qkv, kv, pos, self._inv_freq(x2d.device), self.rotary_scaling)
+                ops.rope_append_decode(qkv, kv, pos, self._inv_freq(x2d.device), self.rotary_scaling, **rk)
             else:
                 cos, sin = getattr(cache, "_rot_dyn", None) or self._rotary_dyn(pos)
-                ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin)
+                ops.rope_(qkv.view(1, B, 3, H, hd), cos, sin, **rk)
                 kv[self._row_index(B, x2d.device), pos] = qkv[:, 0, 1:3]
-            a = ops.attention_decode(q, kv[:, :, 0], kv[:, :, 1], pos=pos).view(B, D)
+            a = ops.attention_decode(q, kv[:, :, 0], kv[:, :, 1], pos=pos, **ak).view(B, D)
         else:
             cos, sin = self._rotary(off, T, x2d.device)
-            ops.rope_(qkv, cos, sin)
+            ops.rope_(qkv, cos, sin, **rk)
             if cache is not None:
                 kv = self._kv_buffer(cache, i, B, off + T, qkv)
                 kv[:B, off:off + T].copy_(qkv[:, :, 1:3])
@@ -538,9 +679,9 @@ class StripedHyena(nn.Module):
             else:
                 k, v = qkv[:, :, 1], qkv[:, :, 2]
             if T == 1 and cache is not None:
-                a = ops.attention_decode(q, k, v).view(B, D)            # split-K over the KV cache
+                a = ops.attention_decode(q, k, v, **ak).view(B, D)      # split-K over the KV cache
             else:
-                a = ops.attention(q, k, v, off).view(B * T, D)
+                a = ops.attention(q, k, v, off, **ak).view(B * T, D)
         if nf:
             return self._mlp_residual_rs_(blk, x2d, self._mixer_out_rs_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias))
         self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, a, mha.out_proj.weight, mha.out_proj.bias, mfma=True),

@@ -325,7 +325,8 @@ class SequenceParallelScorer:
         nb_max, nb_min = (B + G_ - 1) // G_, max(1, B // G_)
         ztm = getattr(ops, "hyena_mfma", False) and getattr(ops, "hyena_ct_flag", False) and hasattr(ops, "hyena_ct") \
             and m._mfma_hyena_ok(nb_max, Tl) and m._mfma_hyena_ok(nb_min, t_min) and m._mfma_hyena_ok(nb_max, t_min) \
-            and m._mfma_hyena_ok(nb_min, Tl) and ops.zt_shape_ok(B, Tl, 3 * D, D) and ops.zt_shape_ok(B, t_min, 3 * D, D) and t_min >= 2
+            and m._mfma_hyena_ok(nb_min, Tl) and ops.zt_shape_ok(B, Tl, 3 * D, D) and ops.zt_shape_ok(B, t_min, 3 * D, D) and t_min >= 2 \
+            and m._table_ok(blk)                              # (the filter fits the operand tables: a property of the weights, the same on every rank)
         w_p, b_p = blk.projections.weight.data, (None if blk.projections.bias is None else blk.projections.bias.data)
         table = m._mfma_table(blk) if ztm else None
         # norms folded into the dense layers (a rank-local choice: no collective depends on it -- the last, shorter shard may differ)
@@ -433,7 +434,9 @@ class SequenceParallelScorer:
             n1 = ops.rmsnorm(x2d, None, blk.pre_norm.scale, m.eps)
             qkv = ops.linear(n1, mha.Wqkv.weight, mha.Wqkv.bias, mfma=True).view(B, Tloc, 3, H, hd)
         cos, sin = m._rotary(t0, Tloc, x2d.device)
-        ops.rope_(qkv, cos, sin)
+        pre = bool(getattr(ops, "attn_prescale", False)) and hasattr(ops, "attn_q_scale")     # (sh/model.py _attn_block)
+        self._ak = {"prescaled": True} if pre else {}
+        ops.rope_(qkv, cos, sin, **({"q_scale": ops.attn_q_scale(hd)} if pre else {}))
         if self.attn_mode != "allgather" and H % self.world == 0 and hasattr(self.comm, "all_to_all"):
             a = self._attn_ulysses(qkv, B, Tloc, Tl, T)
         else:
@@ -472,7 +475,7 @@ class SequenceParallelScorer:
                 full = self._buf(("a2a_full", g), (nb, R, Tl, 3, Hr, hd), qkv)
                 full.copy_(recv.permute(1, 0, 2, 3, 4, 5))
                 full = full.view(nb, R * Tl, 3, Hr, hd)
-            o = ops.attention(full[:, :T, 0], full[:, :T, 1], full[:, :T, 2], 0)           # [nb, T, Hr, hd], this rank's heads
+            o = ops.attention(full[:, :T, 0], full[:, :T, 1], full[:, :T, 2], 0, **self._ak)   # [nb, T, Hr, hd], this rank's heads
             ret = self._buf(("a2a_ret", g), (R, nb, Tl, Hr, hd), o)
             if R * Tl == T:
                 ret.copy_(o.view(nb, R, Tl, Hr, hd).permute(1, 0, 2, 3, 4))
@@ -511,7 +514,7 @@ class SequenceParallelScorer:
         for b in range(B):
             works[b].wait()
             kvg = bufs[b].view(self.world * Tl, 2, H, hd)[:n_keys]
-            a[b:b + 1] = ops.attention(qkv[b:b + 1, :, 0], kvg[None, :, 0], kvg[None, :, 1], t0)
+            a[b:b + 1] = ops.attention(qkv[b:b + 1, :, 0], kvg[None, :, 0], kvg[None, :, 1], t0, **self._ak)
         return a
 
     # ------------------------------------------------------------------ forward / scoring

@@ -42,7 +42,10 @@ extern "C" {
  *   9: the RMSNorm passes folded into the dense layers around them: evo_linear_mfma_nf_bf16, evo_linear_xblk_mfma_nf_bf16,
  *      evo_mlp_gate_mfma_nf_bf16, evo_linear_t_mfma_nf_bf16 (the same launches with a per-row factor in / the rows' sums of squares
  *      out) and evo_rms_finalize_f32 added; no signature changed.
- *  10: evo_probe_copy_f4 and evo_probe_mfma_bf16 added (the box-calibration probes of bench.py's `box` block); no signature changed. */
+ *  10: evo_probe_copy_f4 and evo_probe_mfma_bf16 added (the box-calibration probes of bench.py's `box` block); evo_mlp_gate_small_m_bf16 and
+ *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set);
+ *      evo_rope_qk_bf16 and evo_rope_append_decode_bf16 gained `q_scale`, evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 accept
+ *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply). */
 #define EVO_ABI_VERSION 10
 int evo_abi_version(void);
 
@@ -169,9 +172,12 @@ int evo_hyena_step(const void* z_t, void* fir_state, float* iir_state,
  * replaces flash_attn's Triton rotary kernel               [REF evo/configs/evo-1-131k-base_inference.yml:39-40]
  * NeoX (non-interleaved) pairs (i, i+hd/2), in place on the q and k thirds of a packed
  * qkv [B, T, 3, H, hd] bf16.  cos/sin [T, hd/2] f32 are host-built for absolute positions
- * pos0..pos0+T-1 (already divided by the interpolation factor, already rounded to bf16 values). */
+ * pos0..pos0+T-1 (already divided by the interpolation factor, already rounded to bf16 values).
+ * q_scale (ABI 10; > 0): the rotated QUERY rows are multiplied by it before their one rounding -- the caller passes
+ * softmax_scale * log2(e) and then calls evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 with softmax_scale = 0 ("queries pre-scaled":
+ * a score is an exponent, the prefill kernel's per-score multiply disappears); 1.0 = plain rotary (exact: the bits of ABI 9). */
 int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t,
-                     int64_t B, int64_t T, int64_t H, int64_t hd, void* stream);
+                     int64_t B, int64_t T, int64_t H, int64_t hd, float q_scale, void* stream);
 
 /* decode form: rotary on the q and k rows of ONE token per stream, each at its own position, and the append of (k, v) to
  * the KV cache, in one launch                                  [REF evo/generation.py:138-155; flash_attn_with_kvcache's
@@ -182,7 +188,7 @@ int evo_rope_qk_bf16(void* qkv, const float* cos_t, const float* sin_t,
  *   Bit-identical to evo_rope_qk_bf16 with a table for those positions followed by the indexed copy. */
 int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const float* inv_freq, float scaling,
                                 int64_t B, int64_t H, int64_t hd, int64_t kv_sb, int64_t kv_st, int64_t kv_sw, int64_t kv_sh,
-                                void* stream);
+                                float q_scale, void* stream);
 
 /* ---- causal multi-head attention forward ------------------------------------------------------------
  * replaces flash_attn_2_cuda fwd / flash_attn_with_kvcache  [REF README.md:47-50; evo/configs/evo-1-8k-base_inference.yml:9,30]
@@ -192,7 +198,9 @@ int evo_rope_append_decode_bf16(void* qkv, void* kv, const int64_t* pos, const f
  *   position of query 0 minus absolute position of key 0).
  *   vt_ws: caller-owned workspace of B * H * 128 * (Tk rounded up to 64) bf16, or NULL.  Query ranges longer than 128 rows run
  *   the 64-rows-per-wave kernel (csrc/attn_w64.hip: one wave per SIMD, K / V tiles through LDS-DMA rings), which reads V^T:
- *   a pre-pass launch writes it into vt_ws.  With vt_ws == NULL (or Tq <= 128) the kernels of rounds 1-4 run (csrc/attn.hip). */
+ *   a pre-pass launch writes it into vt_ws.  With vt_ws == NULL (or Tq <= 128) the kernels of rounds 1-4 run (csrc/attn.hip).
+ *   softmax_scale <= 0 (ABI 10): the queries carry softmax_scale * log2(e) already (evo_rope_qk_bf16's q_scale) -- scores are taken as
+ *   exponents in the log2 domain; same for evo_attn_decode_bf16. */
 int evo_attn_fwd_causal_bf16(const void* q, const void* k, const void* v, void* o,
                              int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t q_pos0,
                              int64_t q_sb, int64_t q_st, int64_t q_sh,
@@ -295,12 +303,14 @@ int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w
  * replaces the l1 / l2 GEMV pair + gelu * mul of the single-token forward   [REF evo/configs/evo-1-8k-base_inference.yml:38;
  *                                                                          evo/generation.py:151-155]
  * a [M, I] bf16 = gelu_erf(x . W1^T) * (x . W2^T) with w12 [2I, K] = [W1; W2] bf16, x [M, K] bf16; 1 <= M <= 4,
- * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them. */
-int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, void* stream);
+ * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them.
+ * `grouped` != 0 (ABI 10): w12 is given in the row order of evo_mlp_gate_mfma_bf16's w12g -- blocks of 64 rows = 32 rows of W1 followed
+ * by the same 32 rows of W2 (I % 32 == 0) -- so that ONE copy of l1 | l2 serves the prefill launch and the decode launches. */
+int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, int64_t grouped, void* stream);
 /* same with the post-mixer RMSNorm folded in: x is the residual row, `scale` [K] the norm weight (bit-identical to
  * evo_rmsnorm_bf16 followed by evo_mlp_gate_small_m_bf16); this form also takes 5 <= M <= 8 at K = 4096. */
 int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, const void* w12, void* a, int64_t M, int64_t I,
-                                   int64_t K, float eps, void* stream);
+                                   int64_t K, float eps, int64_t grouped, void* stream);
 
 /* ---- gated MLP activation ---------------------------------------------------------------------------
  * replaces ATen gelu + mul                                  [REF evo/configs/evo-1-8k-base_inference.yml:38]

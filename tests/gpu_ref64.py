@@ -17,7 +17,7 @@ def _bf(x):
 
 
 def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128, z_halo=None, s0=None, ref_rounding=False,
-                  want_state=True):
+                  want_state=True, want_scale=False):
     """fp64 GPU restatement of oracle.op_hyena / RefStripedHyena.hyena_filter_parallel (FIR + split + x1*v + FFT long
     convolution + D skip + gate) on device tensors, evaluated per batch row in chunks of `chunk` channels of one head so
     that the complex128 FFT buffers stay ~1 GB.  z [B,T,3D] (any float dtype, reference column order).
@@ -25,7 +25,9 @@ def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128, z_halo=
     after x1*v, after the convolution, after every op of (y + x1v*D) * x2) -- the accuracy of the reference's own
     arithmetic against fp64, i.e. the floor an engine output is judged against.
     `z_halo` [B,2,3D]: the two rows before the first; `s0` [B,D,8] complex: modal state before the first row.
-    Returns y [B,T,D] float64 and the end state [B,D,8] complex128 (None unless want_state)."""
+    Returns y [B,T,D] float64 and the end state [B,D,8] complex128 (None unless want_state); with `want_scale` also [D]: per channel the
+    largest (|conv| + |x1v * D|) * |x2| over the batch -- the size of the TERMS an output is the sum of (equal to the output's own scale
+    unless the convolution cancels the skip term)."""
     B, T, D3 = z.shape
     D = D3 // 3
     hd = D // H
@@ -33,6 +35,7 @@ def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128, z_halo=
     rnd = _bf if ref_rounding else (lambda x: x)
     y = torch.empty(B, T, D, dtype=torch.float64, device=z.device)
     st = torch.empty(B, D, 8, dtype=torch.complex128, device=z.device) if want_state else None
+    nat = torch.zeros(D, dtype=torch.float64, device=z.device) if want_scale else None
     t = torch.arange(T, dtype=torch.float64, device=z.device)
     w = fir_w.double()
     for h in range(H):
@@ -59,6 +62,8 @@ def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128, z_halo=
                     s0c = s0[b, dsl].to(torch.complex128)
                     conv = conv + torch.einsum("cs,cst->ct", r * p * s0c, pw).real
                 conv = rnd(conv)
+                if want_scale:
+                    nat[dsl] = torch.maximum(nat[dsl], ((conv.abs() + (x1v * dskip[dsl].double()[:, None]).abs()) * x2.abs()).amax(-1))
                 y[b, :, dsl] = rnd(rnd(conv + rnd(x1v * dskip[dsl].double()[:, None])) * x2).t()
                 if want_state:
                     e = torch.einsum("ct,cst->cs", x1v.to(torch.complex128), pw.flip(-1))
@@ -67,7 +72,7 @@ def gpu_fft_hyena(z, fir_w, fir_b, poles, residues, dskip, H, chunk=128, z_halo=
                     st[b, dsl] = e
                 del f, x2, x1, v, x1v, conv
             del pw, hf
-    return y, st
+    return (y, st, nat) if want_scale else (y, st)
 
 
 # ---- blocks (RefStripedHyena.hyena_block / attn_block, mode "fp64") on a SUBSET of output rows -----------------------------

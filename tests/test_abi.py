@@ -69,7 +69,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 250, 64, 1e-6, 100, 104, 100, 0, None) == -1     # M % T
     assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 200, 64, 1e-6, 100, 96, 96, 100, None) == -1     # tail rows inside the main rows
     lib.evo_rope_append_decode_bf16.restype = ctypes.c_int
-    assert lib.evo_rope_append_decode_bf16(None, None, None, None, ctypes.c_float(1.0), 1, 32, 128, 8, 8, 8, 8, None) == -1   # null tensors
+    assert lib.evo_rope_append_decode_bf16(None, None, None, None, ctypes.c_float(1.0), 1, 32, 128, 8, 8, 8, 8, ctypes.c_float(1.0), None) == -1   # null tensors
     assert lib.evo_attn_fwd_causal_bf16(None, None, None, None, 1, 1, 4, 4, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, None, None) == -1
 
 

@@ -389,7 +389,8 @@ def test_hyena_ct_shard_8x16385_full_width_with_halo_and_carry_vs_fft():
     assert srel <= 2e-5 and srel <= floor_srel and srel1 <= 2e-5
 
 
-def test_attention_h32_t8193_vs_eager_fp64():
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_h32_t8193_vs_eager_fp64(pre):
     """BASELINE configs[1] attention shape (one batch row, all 32 heads, T = 8,193) vs eager softmax attention in
     fp64 on the GPU (TEST INFRASTRUCTURE; FlashAttention-2 numerics tolerance: P is rounded to bf16)."""
     from evo_amd.ops import HipOps
@@ -397,11 +398,18 @@ def test_attention_h32_t8193_vs_eager_fp64():
     g = torch.Generator(device=DEV).manual_seed(23)
     T, H = 8193, 32
     qkv = torch.randn(1, T, 3, H, 128, generator=g, device=DEV).bfloat16()
-    o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
+    c = ops.attn_q_scale(128)
+    if pre:            # round 6, the model's default: queries pre-scaled by softmax_scale * log2(e) (one rounding), scores taken as exponents
+        qp = (qkv[:, :, 0].float() * c).bfloat16()
+        o = ops.attention(qp, qkv[:, :, 1], qkv[:, :, 2], 0, prescaled=True)
+    else:
+        o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0)
     mask = torch.ones(T, T, dtype=torch.bool, device=DEV).triu(1)
     worst_rl2, worst_abs = 0.0, 0.0
     for h in range(H):
         q, k, v = (qkv[0, :, i, h].double() for i in range(3))
+        if pre:
+            q = qp[0, :, h].double() / c
         sc = (q @ k.t()) / math.sqrt(128.0)
         sc.masked_fill_(mask, float("-inf"))
         ref = torch.softmax(sc, -1) @ v
@@ -409,12 +417,13 @@ def test_attention_h32_t8193_vs_eager_fp64():
         worst_rl2 = max(worst_rl2, ((got - ref).norm() / ref.norm()).item())
         worst_abs = max(worst_abs, ((got - ref).abs() - ref.abs() * 2 ** -7).max().item())
         del sc, ref
-    print(f"[attention H=32 T=8193] worst head rel-L2 {worst_rl2:.3e}, worst |err| - 2^-7|ref| = {worst_abs:.3e}")
+    print(f"[attention H=32 T=8193{' pre-scaled q' if pre else ''}] worst head rel-L2 {worst_rl2:.3e}, worst |err| - 2^-7|ref| = {worst_abs:.3e}")
     assert worst_rl2 < 4e-3
     assert worst_abs < 2e-2
 
 
-def test_attention_h32_t131073_vs_eager_fp64():
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_h32_t131073_vs_eager_fp64(pre):
     """BASELINE configs[2] attention shape: one row, all 32 heads, T = 131,073 -- the pipelined kernel walks up to 2,049
     key tiles per query block.  768 query rows (the first block, a block in the middle, the last 256 rows) of the full
     launch, and a launch that STARTS at q_pos0 = 98,305 (a sequence-parallel shard / cache continuation), vs chunked eager
@@ -425,20 +434,25 @@ def test_attention_h32_t131073_vs_eager_fp64():
     T, H = 131073, 32
     qkv = torch.randn(1, T, 3, H, 128, generator=g, device=DEV).bfloat16()
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    o = ops.attention(q, k, v, 0)
+    kw = {}
+    if pre:
+        c = ops.attn_q_scale(128)
+        q = (q.float() * c).bfloat16()
+        kw = {"prescaled": True}
+    o = ops.attention(q, k, v, 0, **kw)
     off = 98305
-    o_tail = ops.attention(q[:, off:], k, v, off)
+    o_tail = ops.attention(q[:, off:], k, v, off, **kw)
     assert torch.equal(o_tail, o[:, off:])                               # same tiles in the same order: bit identical
     rows = torch.cat([torch.arange(0, 256), torch.arange(65408, 65664), torch.arange(T - 256, T)]).to(DEV)
     t0 = time.time()
-    ref = causal_attention64(q[0, rows], k[0], v[0], rows)               # [768, 32, 128] fp64
+    ref = causal_attention64(q[0, rows].double() / c if pre else q[0, rows], k[0], v[0], rows)               # [768, 32, 128] fp64
     torch.cuda.synchronize()
     got = o[0, rows].double()
     worst_rl2 = max(((got[:, h] - ref[:, h]).norm() / ref[:, h].norm()).item() for h in range(H))
     worst_abs = ((got - ref).abs() - ref.abs() * 2 ** -7).max().item()
     # late rows average ~1e5 values: |o| ~ 1/sqrt(n) -- judge the error against the row's own scale too
     row_rl2 = ((got - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()
-    print(f"[attention H=32 T=131073] 768 rows vs fp64 ({time.time() - t0:.1f} s): worst head rel-L2 {worst_rl2:.3e}, "
+    print(f"[attention H=32 T=131073{' pre-scaled q' if pre else ''}] 768 rows vs fp64 ({time.time() - t0:.1f} s): worst head rel-L2 {worst_rl2:.3e}, "
           f"worst row rel-L2 {row_rl2:.3e}, worst |err| - 2^-7|ref| = {worst_abs:.3e}")
     assert worst_rl2 < 4e-3 and row_rl2 < 8e-3
     assert worst_abs < 2e-2

@@ -81,7 +81,8 @@ def test_scoring_step_8x8193_is_deterministic_and_finite():
     assert (a <= 0).all()
 
 
-def test_attention_pipelined_kernel_is_reproducible_across_launches_and_query_offsets(ops):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_pipelined_kernel_is_reproducible_across_launches_and_query_offsets(ops, pre):
     """Hazard stress for the pipelined kernel: hand-written v_max3 on MFMA accumulators used to
     depend on timing.  Eight launches on the same data must be bit-identical, and query ranges that START on a
     non-diagonal first tile (q_pos0 > 0: the prologue's QK^T feeds the row max directly) must reproduce the same rows
@@ -90,12 +91,21 @@ def test_attention_pipelined_kernel_is_reproducible_across_launches_and_query_of
     T, H = 16385, 32
     qkv = torch.randn(1, T, 3, H, 128, generator=g, device=DEV).bfloat16()
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    full = ops.attention(q, k, v, 0)
+    kw = {}
+    if pre:                                                  # round 6: queries pre-scaled by softmax_scale * log2(e), scores taken as exponents
+        c = ops.attn_q_scale(128)
+        qs = (q.float() * c).bfloat16()
+        kw = {"prescaled": True}
+    else:
+        qs = q
+    full = ops.attention(qs, k, v, 0, **kw)
     for _ in range(7):
-        assert torch.equal(ops.attention(q, k, v, 0), full)
+        assert torch.equal(ops.attention(qs, k, v, 0, **kw), full)
     for off in (256, 1000, 4097, 12289, T - 257):
-        part = ops.attention(q[:, off:], k, v, off)
+        part = ops.attention(qs[:, off:], k, v, off, **kw)
         assert torch.equal(part, full[:, off:]), off
+    if pre:
+        q = qs.float() / c                                  # (the eager check below un-scales the rounded queries)
     # and against eager fp32 attention on a few query rows spread over the sequence (full key range, all heads)
     rows = torch.tensor([0, 63, 64, 255, 256, 4096, 8191, T - 1], device=DEV)
     for h in (0, 13, 31):

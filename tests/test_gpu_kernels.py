@@ -89,6 +89,14 @@ def test_rope(ops, B, T, H, hd, scaling):
     got = ops.rope_(qkv.to(DEV).clone(), cos.to(DEV), sin.to(DEV))
     assert torch.equal(got[:, :, 2].cpu(), qkv[:, :, 2])        # v untouched
     assert_close_bf16(got, ref)
+    # q_scale (round 6): the rotated QUERIES times the factor, one rounding; k and v as before, bit for bit; 1.0 is the plain launch
+    c = ops.attn_q_scale(hd)
+    got_s = ops.rope_(qkv.to(DEV).clone(), cos.to(DEV), sin.to(DEV), q_scale=c)
+    assert torch.equal(got_s[:, :, 1:], got[:, :, 1:])
+    ref_s = ref.clone()
+    ref_s[:, :, 0] *= c
+    assert_close_bf16(got_s, ref_s)
+    assert torch.equal(ops.rope_(qkv.to(DEV).clone(), cos.to(DEV), sin.to(DEV), q_scale=1.0), got)
 
 
 @pytest.mark.parametrize("M,I", [(7, 64), (33, 10928)])
@@ -356,6 +364,18 @@ def test_hyena_step_matches_oracle_and_prefill(ops):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+def _attn(ops, q, k, v, off, pre):
+    """(engine output, fp64 oracle output).  `pre` (round 6): the queries carry softmax_scale * log2(e) (what evo_rope_qk_bf16's q_scale
+    folds into its one rounding: here bf16(q c)), the kernels take scores as exponents (csrc/attn_w64.hip PRE; softmax_scale = 0 in the C
+    ABI) -- the oracle is given the SAME rounded queries, un-scaled in fp64."""
+    if not pre:
+        return ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), off), R.op_attention(q, k, v, off)
+    c = ops.attn_q_scale(128)
+    qp = (q.float() * c).bfloat16()
+    return ops.attention(qp.to(DEV), k.to(DEV), v.to(DEV), off, prescaled=True), R.op_attention(qp.double() / c, k, v, off)
+
+
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("B,H,Tq,Tk,off", [
     (2, 2, 37, 37, 0),            # one ragged tile
     (1, 2, 513, 513, 0),          # BASELINE configs[0] length
@@ -365,12 +385,12 @@ def test_hyena_step_matches_oracle_and_prefill(ops):
     (1, 2, 64, 200, 136),         # chunk continuation
     (1, 1, 130, 700, 570),        # sequence-parallel shard: local queries, gathered keys
 ])
-def test_attention_matches_oracle(ops, B, H, Tq, Tk, off):
+def test_attention_matches_oracle(ops, B, H, Tq, Tk, off, pre):
     q = bf(torch.randn(B, Tq, H, 128, generator=gen(20)))
     k = bf(torch.randn(B, Tk, H, 128, generator=gen(21)))
     v = bf(torch.randn(B, Tk, H, 128, generator=gen(22)))
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), off)
-    assert_close_bf16(o, R.op_attention(q, k, v, off), rl2=4e-3, atol=2e-2)
+    o, ref = _attn(ops, q, k, v, off, pre)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
 
 
 def test_attention_packed_qkv_views_and_kv_cache_layout(ops):
@@ -385,7 +405,8 @@ def test_attention_packed_qkv_views_and_kv_cache_layout(ops):
     assert torch.equal(o2, o)
 
 
-def test_attention_outlier_scores(ops):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_outlier_scores(ops, pre):
     """Large score outliers late in the key range force big running-max jumps (the rescale path)."""
     B, H, T = 1, 1, 384
     q = bf(torch.randn(B, T, H, 128, generator=gen(24)))
@@ -393,15 +414,17 @@ def test_attention_outlier_scores(ops):
     v = bf(torch.randn(B, T, H, 128, generator=gen(26)))
     k[0, 200, 0] = q[0, 300, 0] * 3       # key 200 dominates query 300 (and nearby rows see a huge score)
     k[0, 70, 0] = q[0, 90, 0] * 2
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
-    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+    o, ref = _attn(ops, q, k, v, 0, pre)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
 
 
-def test_attention_reference_point_moves_several_times_in_one_row(ops):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_reference_point_moves_several_times_in_one_row(ops, pre):
     """The 64-rows-per-wave kernel keeps a row's reference point until a tile's largest exponent exceeds it by W_THR = 32 log2 units
     (csrc/attn_w64.hip); a staircase of spikes 1.5 x, 3 x, 5 x, 8 x |q|^2 (steps of 24-49 units, one per key tile and later) walks the
     rescale path four times in the same row, a -5 x spike on the row's FIRST key starts it 81 units below, and the neighbours in the
-    wave stay put (alpha = 1 exactly)."""
+    wave stay put (alpha = 1 exactly).  `pre` (queries pre-scaled, reference points start at 0 and move beyond +-64 units only): the 5 x and
+    8 x spikes (80 / 130 units) move the staircase row twice, from then on the wave adds its rows' offsets in the burst path."""
     B, H, T = 1, 2, 900
     q = bf(torch.randn(B, T, H, 128, generator=gen(124)))
     k = bf(torch.randn(B, T, H, 128, generator=gen(125)))
@@ -410,14 +433,14 @@ def test_attention_reference_point_moves_several_times_in_one_row(ops):
         k[0, key, 0] = q[0, 850, 0] * mul
     k[0, 0, 1] = q[0, 640, 1] * -5.0
     k[0, 600, 1] = q[0, 640, 1] * 4.0
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
-    ref = R.op_attention(q, k, v, 0)
+    o, ref = _attn(ops, q, k, v, 0, pre)
     assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
     assert_close_bf16(o[:, 850], ref[:, 850], rl2=4e-3, atol=2e-2)                  # the staircase row itself
     assert_close_bf16(o[:, 640], ref[:, 640], rl2=4e-3, atol=2e-2)
 
 
-def test_attention_wide_scores_like_the_models_block_8(ops):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_wide_scores_like_the_models_block_8(ops, pre):
     """Scores with a standard deviation of ~9 log2 units (q, k of rms 2.5: what the synthetic 7B model hands block 8,
     tools/attn_instep_ab.py --model): softmax rows are dominated by a handful of keys, the running maximum climbs ~20 units along a
     row.  Every output row against the fp64 oracle."""
@@ -425,17 +448,34 @@ def test_attention_wide_scores_like_the_models_block_8(ops):
     q = bf(torch.randn(B, T, H, 128, generator=gen(127)) * 2.5)
     k = bf(torch.randn(B, T, H, 128, generator=gen(128)) * 2.5)
     v = bf(torch.randn(B, T, H, 128, generator=gen(129)))
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
-    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+    o, ref = _attn(ops, q, k, v, 0, pre)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
 
 
-def test_attention_4k_causal(ops):
+@pytest.mark.parametrize("shift", [-5.0, -1.2, 3.5])
+def test_attention_prescaled_reference_point_leaves_zero_on_the_first_tile(ops, shift):
+    """PRE form only: every score of a head sits `shift` x |u|^2 (x softmax_scale log2 e: -81 / -19.6 / +57 log2 units) away from 0 -- all
+    queries ~ u, all keys ~ shift u.  At -81 a row's FIRST visible tile pulls its reference point down (nothing accumulated yet: no
+    rescale); at -19.6 and +57 the reference stays at 0 and P = 2^s runs at 2^-20 / 2^57 through the bf16 P and the fp32 sums."""
+    B, H, T = 1, 2, 1500
+    u = torch.randn(128, generator=gen(130))
+    u = u / u.norm() * math.sqrt(128.0)
+    q = bf(u[None, None, None, :] + 0.05 * torch.randn(B, T, H, 128, generator=gen(131)))
+    k = bf(shift * u[None, None, None, :] + 0.3 * torch.randn(B, T, H, 128, generator=gen(132)))
+    v = bf(torch.randn(B, T, H, 128, generator=gen(133)))
+    o, ref = _attn(ops, q, k, v, 0, True)
+    assert torch.isfinite(o.float()).all()
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_4k_causal(ops, pre):
     B, H, T = 1, 2, 4099
     q = bf(torch.randn(B, T, H, 128, generator=gen(27)))
     k = bf(torch.randn(B, T, H, 128, generator=gen(28)))
     v = bf(torch.randn(B, T, H, 128, generator=gen(29)))
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0)
-    assert_close_bf16(o, R.op_attention(q, k, v, 0), rl2=4e-3, atol=2e-2)
+    o, ref = _attn(ops, q, k, v, 0, pre)
+    assert_close_bf16(o, ref, rl2=4e-3, atol=2e-2)
 
 
 # ------------------------------------------------------------------------------------------------ decode attention
@@ -451,6 +491,12 @@ def test_attention_decode_matches_oracle(ops, B, H, Tk, splits):
     pos = torch.tensor([Tk - 1], dtype=torch.int64, device=DEV)
     o2 = ops.attention_decode(q.to(DEV), kvd[:, :, 0], kvd[:, :, 1], pos=pos, n_splits=splits)
     assert_close_bf16(o2, ref, rl2=4e-3, atol=2e-2)
+    # queries pre-scaled by softmax_scale * log2(e) (round 6: what the model's rotary launch hands over), softmax_scale = 0 in the C ABI
+    c = ops.attn_q_scale(128)
+    qp = (q.float() * c).bfloat16()
+    ref_p = R.op_attention(qp.double() / c, kv[:, :Tk, 0], kv[:, :Tk, 1], Tk - 1)
+    o3 = ops.attention_decode(qp.to(DEV), kvd[:, :, 0], kvd[:, :, 1], pos=pos, n_splits=splits, prescaled=True)
+    assert_close_bf16(o3, ref_p, rl2=4e-3, atol=2e-2)
 
 
 @pytest.mark.gpu
@@ -483,6 +529,15 @@ def test_rope_append_decode_is_bitwise_table_rope_and_indexed_copy(positions, sc
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert torch.equal(kv_a, kv_b)
+    # q_scale: the same factor in both launches -> the same bits (queries scaled, k / v / cache untouched by it)
+    c = ops.attn_q_scale(hd)
+    want_s = qkv.clone()
+    ops.rope_(want_s.view(1, B, 3, H, hd), cos, sin, q_scale=c)
+    got_s = qkv.clone()
+    kv_c = torch.zeros_like(kv_a)
+    ops.rope_append_decode(got_s, kv_c[:B], pos, inv, scaling, q_scale=c)
+    assert torch.equal(got_s, want_s) and torch.equal(kv_c, kv_b) and torch.equal(got_s[:, :, 1:], got[:, :, 1:])
+    assert not torch.equal(got_s[:, :, 0], got[:, :, 0])
 
 
 # ---- the single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip): forms of its launch --------------------------------------------

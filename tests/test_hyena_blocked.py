@@ -128,3 +128,43 @@ def test_tables_are_consistent():
     W = sum(x.double() for x in C["W"])
     assert (W[:, 0, HT.L - 1] - 1).abs().max() < 1e-7 and W[:, 1, HT.L - 1].abs().max() < 1e-7      # p^0 = 1
     assert (C["P"][:, 0, 0::2].double() - (p ** HT.L).real).abs().max() < 1e-6
+
+
+def test_table_precision_guard_admits_plain_filters_and_refuses_cancelling_ones():
+    """evo_amd/hyena_tables.py table_precision: the table-build guard of the matrix-core Hyena operator.  Silent on the synthetic law of the
+    bench (long-memory poles), on upstream's init-like |p| = 0.01, on |p| = 1 exactly and on residues of any scale; fires on modes that
+    cancel to 1 % at |p| = 0.5 / 0.9 -- and there the emulated kernel arithmetic indeed leaves the fp32 level (error before the output
+    rounding ~1e-3 of the channel's largest output, a bf16 rounding), while an admitted filter stays at 1e-5."""
+    D = 64
+    g = torch.Generator().manual_seed(1)
+    fir_w, fir_b, poles, res, dskip = params(D, 60)
+    assert HT.table_ok(poles, res, dskip) and HT.table_precision(poles, res, dskip).max() < 1e-4
+
+    def plain(pm, scale):
+        ang = (torch.rand(D, 8, generator=g, dtype=torch.float64) * 2 - 1) * math.pi
+        r = torch.randn(D, 8, 2, generator=g, dtype=torch.float64) * scale
+        return torch.stack([pm * torch.cos(ang), pm * torch.sin(ang)], -1).float().contiguous(), r.float().contiguous()
+
+    def cancelling(pm, frac):
+        ang = (torch.rand(D, 8, generator=g, dtype=torch.float64) * 2 - 1) * math.pi
+        ang[:, 1::2] = ang[:, 0::2] + 1e-3
+        r = torch.randn(D, 8, 2, generator=g, dtype=torch.float64) * 30
+        r[:, 1::2] = -frac * r[:, 0::2]
+        return torch.stack([pm * torch.cos(ang), pm * torch.sin(ang)], -1).float().contiguous(), r.float().contiguous()
+    for pm in (1e-2, 0.5, 0.9, 1.0 - 1e-6, 1.0):
+        for scale in (1e-2, 1.0, 30.0):
+            po, re = plain(pm, scale)
+            assert HT.table_ok(po, re, dskip), (pm, scale, HT.table_precision(po, re, dskip).max())
+    z = torch.randn(1, 1500, 3 * D, generator=torch.Generator().manual_seed(61)).bfloat16()
+    seen = {}
+    for pm in (0.5, 0.9):
+        po, re = cancelling(pm, 0.99)
+        prec = HT.table_precision(po, re, dskip)
+        assert not HT.table_ok(po, re, dskip) and (prec > HT.TABLE_TOL).double().mean() > 0.5, (pm, prec.median())
+        y, _ = emulate_blocked(z, fir_w, fir_b, po, re, dskip, 1)
+        ry, _ = R.op_hyena(z, fir_w, fir_b, po, re, dskip, 1)
+        seen[pm] = ((y.double() - ry).abs().amax((0, 1)) / ry.abs().amax((0, 1))).max().item()
+        assert seen[pm] > 3e-4, seen                                     # the split does lose precision there: the guard is not crying wolf
+    y, _ = emulate_blocked(z, fir_w, fir_b, poles, res, dskip, 1)
+    ry, _ = R.op_hyena(z, fir_w, fir_b, poles, res, dskip, 1)
+    assert ((y.double() - ry).abs().amax((0, 1)) / ry.abs().amax((0, 1))).max().item() < 5e-5
