@@ -92,17 +92,21 @@ def timed(fn, steps, warmup, dist_on, stats=None):
 
 
 def pmc_traffic(kernel, B, T, with_source=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, see
-    profiles/r01_ops_pmc_fetch_write.txt); None for shapes that were not profiled.  PMC counters cannot be
-    collected from inside this process, so this is a recorded measurement, not a live one: `with_source` also returns
-    the commit the passes were taken at (profiles/pmc_traffic.json "_commit"), printed beside the number."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            d = json.load(f)
-        v = d.get(kernel, {}).get(f"B{B}_T{T}")
-        return (v, d.get("_commit", {}).get(kernel)) if with_source else v
-    except (OSError, ValueError):
-        return (None, None) if with_source else None
+    """HBM bytes per launch from rocprofv3 PMC passes (read requests x 128 B + 64-byte writes x 64 + 32-byte writes x 32: MI355X_MICROARCH.md).
+    PMC counters cannot be collected from inside this process.  tools/gpu_check.sh runs the two counter passes right BEFORE this script and
+    leaves gpurun_out/check/pmc_traffic_live.json (same box, same tree: "this run"); without it the committed record
+    profiles/pmc_traffic.json is used.  `with_source` also returns (commit the passes were taken at, "live" | "recorded")."""
+    for path, kind in ((os.path.join(ROOT, "gpurun_out", "check", "pmc_traffic_live.json"), "live"),
+                       (os.path.join(ROOT, "profiles", "pmc_traffic.json"), "recorded")):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            v = d.get(kernel, {}).get(f"B{B}_T{T}")
+            if v is not None:
+                return (v, d.get("_commit", {}).get(kernel), kind) if with_source else v
+        except (OSError, ValueError):
+            continue
+    return (None, None, None) if with_source else None
 
 
 def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
@@ -131,10 +135,11 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
     if "hyena_mfma" in ksum:
         ms = ksum["hyena_mfma"][1]
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        traffic, t_commit = pmc_traffic("hyena_ct_kernel", B, T, with_source=True)
+        traffic, t_commit, t_kind = pmc_traffic("hyena_ct_kernel", B, T, with_source=True)
         return {"kernel": "hyena_ct_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": f"recorded rocprofv3 PMC passes of commit {t_commit} (profiles/pmc_traffic.json), not this run",
+                "traffic_source": (f"rocprofv3 PMC passes of THIS gpu_check run, right before this script (commit {t_commit})" if t_kind == "live" else
+                                   f"recorded rocprofv3 PMC passes of commit {t_commit} (profiles/pmc_traffic.json), not this run"),
                 "z_layout": "channel-major z^T [3 D][B Tp], written by the projection's dense layer launched with swapped operands (a lane's eight "
                             "steps of a channel = 16 contiguous bytes, loaded straight into registers: no window in LDS)",
                 "y_layout": "blocked [B T / 128][D / 16][128][16] (whole cache lines per store; the output projection's dense layer gathers it)",

@@ -67,6 +67,10 @@
 #ifndef W_THRP
 #define W_THRP 64.0f                        // PRE (pre-scaled queries): a row's reference point leaves 0 only beyond +-W_THRP log2 units
 #endif
+#ifndef W_EARLY
+#define W_EARLY 0                           // measurement knob (PRE only): 1 = the exp stream of a tile's FIRST 32 keys (80 of its 160 instructions) runs under the
+                                            // previous trip's P.V MFMAs, speculatively.  MEASURED SLOWER (profiles/r06_attn_notes.txt: 120.1 vs 116.9 ms at 1 x 131,073): see side_early
+#endif
 #ifndef W_VD
 #define W_VD 4                              // V^T fragments read ahead of their MFMAs (5+: the register file spills into AGPR copies)
 #endif
@@ -462,8 +466,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     };
     // side work of P.V gap j: 120 instructions spread at <= 4 per gap; the second-half score tuples (last written by the MFMAs of
     // phase-1 gaps 30 / 31) are first read in gap 8
+    // PRE + W_EARLY (an experiment that LOST, kept as a build knob with its number).  Hypothesis: phase 1 is the long pole -- 64 quarter-rate
+    // v_exp_f32 + ~100 other instructions of the exp stream beside 1,024 MFMA cycles, while phase 2 carries ~130 full-rate ones and, with
+    // the queries pre-scaled, not even the 64 fma (removing those alone bought only 0.7 %).  So half of the NEXT tile's exp stream moves
+    // here: its first 32 keys (tuples kt = 0, deposited 16+ gaps ago) are exponentiated under P.V of the current tile, in the P^T words P.V has
+    // already consumed (group g's words are free behind gap 8 g + 7) -- BEFORE the tile's row maximum is known.  That is safe because
+    // the reference point almost never moves (PRE: only beyond +-64 log2 units); when it does (`upd_any`, gap 28) the early words and
+    // row sums are simply formed again from the re-based exponents.  Correct (every attention test green) and 2.7 % SLOWER than W_EARLY 0 in
+    // the same process: the trip is not bound by where the exp stream sits -- see DESIGN 11.3.
+    //   gaps 0..6, 8..16   row max (kt = 0 elements first: the kt = 1 tuple was deposited in phase-1 gaps 30 / 31)
+    //   gaps 8..17         early exp of 16-key group 0  (40 instructions)        gaps 18..27  ... of group 1
+    //   gaps 17..20        the reference-point bookkeeping                          gap 28       rare: re-base + redo the early groups
+    auto side_early = [&](const int j) __attribute__((always_inline)) {
+        if (j < 7) { max_op(2 * j); max_op(2 * j + 1); }
+        else if (j >= 8 && j <= 16) { max_op(2 * (j - 1)); max_op(2 * (j - 1) + 1); }
+        if (j >= 8 && j <= 27) {
+            const int q = 4 * (j - 8);                                          // 80 instructions, four per gap: groups G = 0..7
+            exp_op(q / 10, q % 10); exp_op((q + 1) / 10, (q + 1) % 10); exp_op((q + 2) / 10, (q + 2) % 10); exp_op((q + 3) / 10, (q + 3) % 10);
+        }
+        if (j == 17) book_a();
+        else if (j == 18) book_b();
+        else if (j == 19) book_c();
+        else if (j == 20) book_d();
+        else if (j == 28) {
+            if (upd_any) {                          // rare: re-base the exponents of the rows that moved, then the early groups once more
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) W_EL(x, r) -= dl[x];
+                w_static_for<80>([&](auto qc) __attribute__((always_inline)) { W_USE3(S, pk, tp); exp_op(decltype(qc)::v / 10, decltype(qc)::v % 10); });
+            }
+        }
+    };
     auto side = [&](const int j) __attribute__((always_inline)) {
         // (no loops here: a loop that contains a pin is unrolled too late for the register promotion of S / ev)
+        if constexpr (PRE && W_EARLY && !W_LSUM_MFMA) { side_early(j); return; }
         if (j < 8) {                                // exponents of the first-half tuples (written >= 16 MFMAs ago); PRE: the scores ARE the exponents
             if constexpr (!PRE) { fma_op(0, 4 * j); fma_op(0, 4 * j + 1); fma_op(0, 4 * j + 2); fma_op(0, 4 * j + 3); }
         } else if (j < 16) {                        // ... of the second-half tuples
@@ -545,7 +582,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         W_NOP24();                                         // MFMA results -> the VALU below
         if (0 >= mask_from) mask_tile(0);
         __builtin_amdgcn_sched_barrier(0);
-        w_static_for<32>([&](auto jc) __attribute__((always_inline)) { side(decltype(jc)::v); });
+        if constexpr (PRE && W_EARLY && !W_LSUM_MFMA) {
+            // tile 0: row max and bookkeeping first, then (re-based if a row moved) the early half of its exp stream -- nothing speculative here
+            w_static_for<32>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::v;
+                if (j < 7) { max_op(2 * j); max_op(2 * j + 1); }
+                else if (j >= 8 && j <= 16) { max_op(2 * (j - 1)); max_op(2 * (j - 1) + 1); }
+            });
+            book_a(); book_b(); book_c(); book_d();
+            if (upd_any) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) W_EL(x, r) -= dl[x];
+            }
+            w_static_for<80>([&](auto qc) __attribute__((always_inline)) { W_USE3(S, pk, tp); exp_op(decltype(qc)::v / 10, decltype(qc)::v % 10); });
+        } else {
+            w_static_for<32>([&](auto jc) __attribute__((always_inline)) { side(decltype(jc)::v); });
+        }
         resc = false;                                      // (O is still zero)
         const uint32_t kb1 = k_rd + 1 * W_KSTAGE;          // tile 1 -> K slot 1: its first-half fragments
         w_static_for<4>([&](auto jc) __attribute__((always_inline)) { W_USE2(kf, kb1); constexpr int ks = decltype(jc)::v; W_DSR_K(kf[ks], kb1, ks * 32); });
@@ -626,8 +680,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #if W_LSUM_MFMA
             exp_op((3 * i) / 6, (3 * i) % 6); exp_op((3 * i + 1) / 6, (3 * i + 1) % 6); exp_op((3 * i + 2) / 6, (3 * i + 2) % 6);
 #else
-            exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
-            exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
+            if constexpr (PRE && W_EARLY) {
+                // the tile's LAST 32 keys only (groups G = 8..15: the first 32 went under the previous trip's P.V): 80 instructions, three
+                // per gap -- done by gap 26, the tuples they read are overwritten by the deposits of gaps 30 / 31
+                if constexpr (3 * i < 80) exp_op(8 + (3 * i) / 10, (3 * i) % 10);
+                if constexpr (3 * i + 1 < 80) exp_op(8 + (3 * i + 1) / 10, (3 * i + 1) % 10);
+                if constexpr (3 * i + 2 < 80) exp_op(8 + (3 * i + 2) / 10, (3 * i + 2) % 10);
+            } else {
+                exp_op((5 * i) / 10, (5 * i) % 10); exp_op((5 * i + 1) / 10, (5 * i + 1) % 10); exp_op((5 * i + 2) / 10, (5 * i + 2) % 10);
+                exp_op((5 * i + 3) / 10, (5 * i + 3) % 10); exp_op((5 * i + 4) / 10, (5 * i + 4) % 10);
+            }
 #endif
 #endif
 #ifndef W_ABL_NODMA

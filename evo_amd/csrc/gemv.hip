@@ -634,61 +634,70 @@ __global__ __launch_bounds__(256) void gemv_gate_kernel(const uint4* __restrict_
 //   D[n][m]: lane holds n = 4 (lane >> 4) + r, m = lane & 15.
 // The eight partial tiles meet in LDS; wave 0 adds bias / residual and stores (one rounding).
 typedef float gv_f32x4 __attribute__((ext_vector_type(4)));
+// MT (round 6): m tiles of 16 batch rows per weight pass -- 17 <= M <= 64 rows (the pooled decode step at 17-64 live slots; small prefill
+// batches) stream the weights ONCE with MT MFMAs per weight fragment.  Until round 5 those batches ran the persistent 256 x 256 GEMM:
+// N / 256 of the 256 CUs busy, 0.5-1.3 TB/s of weights (profiles/r06_pool32_kernel_stats.txt: 80 % of a 32-slot pooled step).
+template <int MT>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                           const uint16_t* __restrict__ bias, const uint16_t* res,
                                                           uint16_t* y, int M, int N, int nvec) {   // res may alias y
-    __shared__ gv_f32x4 part[8][64];
+    __shared__ gv_f32x4 part[MT][8][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kb = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
-    const int mrow = r16 < M ? r16 : M - 1;
     const int nsteps = nvec >> 2;                                // 32 k per MFMA = 4 vectors of 8
     const int s0 = (int)((int64_t)nsteps * wave / 8), s1 = (int)((int64_t)nsteps * (wave + 1) / 8);
     const uint4* wp = w + (int64_t)nrow * nvec + kb;
-    const uint4* xp = x + (int64_t)mrow * nvec + kb;
-    // wave 0 stores: its bias / residual values are requested ahead of the stream (see gemv_kernel)
-    uint16_t pf_b[4] = {0, 0, 0, 0}, pf_r[4] = {0, 0, 0, 0};
-    if (wave == 0 && r16 < M) {
+    const uint4* xp[MT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 4 * kb + r;
-            if (n < N) {
-                if (bias) pf_b[r] = bias[n];
-                if (res) pf_r[r] = res[(int64_t)r16 * N + n];
-            }
-        }
+    for (int t = 0; t < MT; ++t) {
+        const int mrow = 16 * t + r16 < M ? 16 * t + r16 : M - 1;
+        xp[t] = x + (int64_t)mrow * nvec + kb;
     }
-    gv_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    gv_f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = gv_f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = MT == 1 ? 8 : (MT == 2 ? 4 : 2);           // weight fragments in flight per trip (x fragments: U * MT)
     int s = s0;
-    for (; s + 8 <= s1; s += 8) {
-        uint4 wf[8], xf[8];
+    for (; s + U <= s1; s += U) {
+        uint4 wf[U], xf[MT][U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wf[u] = ld_stream(wp + 4 * (s + u));
+        for (int u = 0; u < U; ++u) wf[u] = ld_stream(wp + 4 * (s + u));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xf[u] = xp[4 * (s + u)];
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[u]), __builtin_bit_cast(bf16x8_t, xf[u]),
-                                                          acc, 0, 0, 0);
+            for (int u = 0; u < U; ++u) xf[t][u] = xp[t][4 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[u]), __builtin_bit_cast(bf16x8_t, xf[t][u]),
+                                                                 acc[t], 0, 0, 0);
     }
-    for (; s < s1; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ld_stream(wp + 4 * s)),
-                                                      __builtin_bit_cast(bf16x8_t, xp[4 * s]), acc, 0, 0, 0);
-    part[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0) {
+    for (; s < s1; ++s) {
+        const uint4 wv = ld_stream(wp + 4 * s);
 #pragma unroll
-        for (int q = 1; q < 8; ++q) acc += part[q][lane];
-        const int m = r16;
+        for (int t = 0; t < MT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xp[t][4 * s]), acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) part[t][wave][lane] = acc[t];
+    __syncthreads();
+    // the eight partial tiles of m tile t meet in wave t (MT <= 4 of the 8 waves store): bias / residual added in fp32, one rounding
+    if (wave < MT) {
+        gv_f32x4 a_ = part[wave][0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) a_ += part[wave][q][lane];
+        const int m = 16 * wave + r16;
         if (m < M) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 4 * kb + r;
                 if (n < N) {
-                    float o = acc[r] + (bias ? bf_to_f(pf_b[r]) : 0.f);
-                    if (res) o += bf_to_f(pf_r[r]);
+                    float o = a_[r] + (bias ? bf_to_f(bias[n]) : 0.f);
+                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
                     y[(int64_t)m * N + n] = f_to_bf(o);
                 }
             }
@@ -844,13 +853,16 @@ extern "C" int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, 
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                                        int64_t M, int64_t N, int64_t K, void* stream) {
-    if (M < 1 || M > 16 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
+    if (M < 1 || M > 64 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
     if (M > 8 && K % 32 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (M >= 5 && K % 32 == 0) {
-        hipLaunchKernelGGL(skinny_mfma_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, (const uint4*)x,
-                           (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N,
-                           (int)(K / 8));
+        const dim3 grid((unsigned)((N + 15) / 16)), block(512);
+#define EVO_SK(MT)                                                                                                         \
+        hipLaunchKernelGGL(skinny_mfma_kernel<MT>, grid, block, 0, s, (const uint4*)x, (const uint4*)w, (const uint16_t*)bias,  \
+                           (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)(K / 8))
+        if (M <= 16) EVO_SK(1); else if (M <= 32) EVO_SK(2); else if (M <= 48) EVO_SK(3); else EVO_SK(4);
+#undef EVO_SK
         return evo_launch_status();
     }
     switch (M) {

@@ -278,9 +278,11 @@ class HipOps:
     @staticmethod
     def _use_small_m(x, w):
         """The weight-streaming kernels (csrc/gemv.hip) serve every decode-sized batch: dot2 form up to M = 4 (and
-        for K % 32 != 0 up to M = 8), MFMA form for 5 <= M <= 16 (tools/bench_gemv.py for the crossovers)."""
+        for K % 32 != 0 up to M = 8), MFMA form for 5 <= M <= 16 (tools/bench_gemv.py for the crossovers) and -- round 6 -- for
+        17 <= M <= 64 with 2-4 m tiles per weight pass (the pooled decode step at 17-64 live slots ran the persistent 256 x 256 GEMM
+        there: N / 256 of the 256 CUs busy, 80 % of a 32-slot step; profiles/r06_pool32_kernel_stats.txt)."""
         M, K = x.shape
-        if not (1 <= M <= 16):
+        if not (1 <= M <= (64 if K % 32 == 0 else 16)):
             return False
         if K % 32 != 0 and not (M <= 4 or (M <= 8 and w.shape[0] <= 4096)):
             return False

@@ -45,7 +45,8 @@ extern "C" {
  *  10: evo_probe_copy_f4 and evo_probe_mfma_bf16 added (the box-calibration probes of bench.py's `box` block); evo_mlp_gate_small_m_bf16 and
  *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set);
  *      evo_rope_qk_bf16 and evo_rope_append_decode_bf16 gained `q_scale`, evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 accept
- *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply). */
+ *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply); evo_linear_small_m_bf16
+ *      takes up to 64 rows. */
 #define EVO_ABI_VERSION 10
 int evo_abi_version(void);
 
@@ -228,9 +229,10 @@ int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
 
 /* ---- skinny dense layer (decode) ----------------------------------------------------------------------
  * replaces cuBLAS GEMV-shaped nn.Linear calls of the single-token forward   [REF evo/generation.py:151-155]
- * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 16, K % 8 == 0 (K % 32 == 0 for
- * M > 8), all bf16, fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) forms: dot2 on the VALU up to
- * M = 4, v_mfma_f32_16x16x32_bf16 with the batch rows on the MFMA's N side from M = 5; `residual` may alias `y`. */
+ * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 64 (ABI 10; 16 before), K % 8 == 0 (K % 32 == 0
+ * for M > 8), all bf16, fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) forms: dot2 on the VALU up to
+ * M = 4, v_mfma_f32_16x16x32_bf16 with the batch rows on the MFMA's N side from M = 5 -- one to four tiles of 16 rows per weight pass
+ * (17-64 rows: the pooled decode step of 17-64 live streams); `residual` may alias `y`. */
 int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
                             int64_t M, int64_t N, int64_t K, void* stream);
 

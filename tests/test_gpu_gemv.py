@@ -1,5 +1,5 @@
-"""GPU (-m gpu): the skinny (M <= 16) weight-streaming dense layers (dot2 and MFMA forms) against fp64 on the same
-bf16 inputs."""
+"""GPU (-m gpu): the skinny (M <= 64) weight-streaming dense layers (dot2 and MFMA forms; round 6: 17-64 rows with 2-4 m tiles per weight
+pass) against fp64 on the same bf16 inputs."""
 import pytest
 import torch
 
@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 11, 16])
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 11, 16, 17, 32, 33, 48, 49, 64])
 @pytest.mark.parametrize("N,K", [(12288, 4096), (4096, 10928), (4096, 11008), (512, 4096), (37, 264), (37, 288)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual"])
 def test_linear_small_m(M, N, K, mode):
@@ -35,6 +35,25 @@ def test_linear_small_m(M, N, K, mode):
     err = (got - ref).abs()
     assert (err <= ref.abs() * 2 ** -8 + 2e-3 * ref.abs().max()).all()
     assert ((got - ref).norm() / ref.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("M,norm", [(1, False), (3, False), (4, True), (8, True), (6, False), (20, False), (20, True)])
+def test_mlp_gate_grouped_weight_layout_is_bitwise_the_plain_layout(M, norm):
+    """One weight set (round 6, ABI 10 `grouped`): the decode gate launches reading l1 | l2 in the gated MFMA launch's row order (blocks of
+    32 rows of W1 | the same 32 of W2: HipOps.pack_gate_weights) give the bits of the plain [W1; W2] order -- weight-streaming launches
+    (M <= 4; <= 8 with the norm) and the unfused fallback (dense layer + un-grouping + gate kernel) alike."""
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    I, K = 11008, 4096
+    g = torch.Generator().manual_seed(M * 31 + 5)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w12 = (torch.randn(2 * I, K, generator=g) * (1.5 / K ** 0.5)).bfloat16().to(DEV)
+    sc = (1.0 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    w12g = ops.pack_gate_weights(w12)
+    kw = dict(norm_scale=sc, eps=1e-6) if norm else {}
+    want = ops.mlp_gate(x, w12, **kw)
+    got = ops.mlp_gate(x, None, w12g=w12g, **kw)
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 6])

@@ -16,9 +16,9 @@ from collections import defaultdict
 
 D, I3, V = 4096, 11008, 512
 BYTES = {  # weights a launch streams at batch 1 (bf16)
-    "gemv_norm_hyena": 3 * D * D * 2,      # pre-norm + projections + FIR / modal step
-    "gemv_norm": 3 * D * D * 2,            # pre-norm + Wqkv
-    "gemv_gate": 2 * I3 * D * 2,           # post-norm + l1 | l2 + gate
+    "gemv_norm_hyena_kernel": 3 * D * D * 2,      # pre-norm + projections + FIR / modal step
+    "gemv_norm_kernel": 3 * D * D * 2,            # pre-norm + Wqkv
+    "gemv_gate_kernel": 2 * I3 * D * 2,           # post-norm + l1 | l2 + gate
 }
 
 
