@@ -799,6 +799,16 @@ def main():
         out["scaling_131k"] = out["ctx131k"].get("scaling")   # BASELINE configs[3]: the sequence-split result, top level
     if n_gpus == 1 and isinstance(out.get("ctx131k"), dict) and "scaling_131k_predicted" in out["ctx131k"]:
         out["scaling_131k_predicted"] = out["ctx131k"].pop("scaling_131k_predicted")
+    # the box's rates once more, compact: inside `config` (a key the driver's record keeps whole) and as the LAST key of the line (its stdout tail)
+    bs = {k: out["box"].get(k) for k in ("hbm_copy_GBs", "mfma_probe_tflops", "library_gemm_tflops", "calibration_factor", "dense_share_of_step")
+          if isinstance(out.get("box"), dict) and k in out["box"]}
+    if bs:
+        ht = out["box"].get("headline_telemetry", {})
+        bs.update({"sclk_MHz_mean_headline": ht.get("sclk_MHz_mean"), "power_W_mean_headline": ht.get("power_W_mean"), "power_cap_W": ht.get("power_cap_W"),
+                   "value_per_calibrated_box": out.get("value_per_calibrated_box"),
+                   "headline_after_legs_value": (out.get("headline_after_legs") or {}).get("value")})
+        out["config"]["box"] = bs
+        out["box_summary"] = bs
     if rank == 0:
         print(json.dumps(out))
     if dist_on:
