@@ -71,6 +71,15 @@
 #define W_EARLY 0                           // measurement knob (PRE only): 1 = the exp stream of a tile's FIRST 32 keys (80 of its 160 instructions) runs under the
                                             // previous trip's P.V MFMAs, speculatively.  MEASURED SLOWER (profiles/r06_attn_notes.txt: 120.1 vs 116.9 ms at 1 x 131,073): see side_early
 #endif
+#ifndef W_PROFILE
+#define W_PROFILE 0                         // 1 (timing build, tools/attn_phase_profile.py): every wave accumulates shader clocks per trip segment and
+                                            // writes them over its first output row's bytes: [resc, phase 1, between, phase 2, waits, barrier, trips]
+#endif
+#if W_PROFILE
+#define W_STAMP(K) { const uint64_t n_ = __builtin_readcyclecounter(); tp_[K] += n_ - tl_; tl_ = n_; }
+#else
+#define W_STAMP(K)
+#endif
 #ifndef W_VD
 #define W_VD 4                              // V^T fragments read ahead of their MFMAs (5+: the register file spills into AGPR copies)
 #endif
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     // Online softmax state of the lane's two rows.  A row's exponentials are taken relative to a reference point -nm (scaled, log2
     // domain) that moves only when a tile's largest exponent exceeds W_THR (or at the row's first visible key); `seen` = it has one.
     float nm[2] = {0.f, 0.f};                     // -(reference point); 0 until the row has seen a key
-    bool seen[2] = {false, false};
+    uint32_t seenm[2] = {0u, 0u};                // per lane: all ones once the row has a reference point (non-PRE) / has seen a key (PRE)
     float alpha[2] = {1.f, 1.f};                  // factor the pending tile applies to O and l when `resc`
     // The softmax denominators ride on the matrix pipe: l^T[.][q] = ones . P^T, one more MFMA per 16-key group and query block (8 of
     // 72 per trip) with an all-ones A fragment.  Every row of the 32 x 32 result holds the column sums of the bf16 P the numerator
@@ -427,42 +436,51 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     };
     // the rows' reference points for tile t+1, in four steps (both query blocks side by side: two independent dependency chains per step)
     float emx[2];
-    bool updv[2];
+    uint32_t updm[2];                             // per lane: all ones = the row's reference point moves for the pending tile
     auto book_a = [&]() __attribute__((always_inline)) {                        // the row's largest exponent in this tile (-inf: all masked)
         emx[0] = w_xor32_max(tmx[0]); emx[1] = w_xor32_max(tmx[1]);
         W_PIN(emx[0]); W_PIN(emx[1]);
     };
     bool any_nm = false;                          // PRE, wave-uniform: some row of the wave has left the reference point 0
-    bool got[2] = {false, false};                 // PRE: the tile has a visible key for the row
+    uint32_t gotm[2] = {0u, 0u};                  // PRE: the tile has a visible key for the row
+    // The per-row decisions are written as 32-bit lane MASKS and bitwise arithmetic, not as bool expressions (round 6): from `a ? b : c` and
+    // `a || b` on per-lane bools hipcc built s_and_saveexec / s_or exec regions, and every write of EXEC in the middle of the MFMA stream waits
+    // for the matrix pipe to drain -- eight of them per trip cost ~660 of a trip's 3,880 cycles (tools/attn_phase_profile.py with
+    // -DW_ABL_NOBOOK: phase 2 1,715 -> 1,056 cycles; profiles/r06_attn_notes.txt).  Selects on masks are v_cmp + v_cndmask: no EXEC write.
     auto book_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
+            const float e = emx[x];
+            const uint32_t got_ = e > -INFINITY ? 0xffffffffu : 0u;
             if constexpr (PRE) {
                 // the reference stays where it is (0 from the start) while the tile's largest exponent is inside +-W_THRP; a row's FIRST
                 // visible tile may also pull it down (nothing is accumulated yet: alpha = 0 below, nothing is rescaled)
-                got[x] = emx[x] > -INFINITY;
-                updv[x] = (emx[x] > W_THRP) || (!seen[x] && got[x] && emx[x] < -W_THRP);
+                const uint32_t up_ = e > W_THRP ? 0xffffffffu : 0u, lo_ = e < -W_THRP ? 0xffffffffu : 0u;
+                gotm[x] = got_;
+                updm[x] = up_ | (~seenm[x] & got_ & lo_);
             } else {
-                updv[x] = seen[x] ? (emx[x] > W_THR) : (emx[x] > -INFINITY);   // (a row's first visible key always sets its reference point)
+                const uint32_t up_ = e > W_THR ? 0xffffffffu : 0u;
+                updm[x] = (seenm[x] & up_) | (~seenm[x] & got_);            // (a row's first visible key always sets its reference point)
             }
-            dl[x] = updv[x] ? emx[x] : 0.f;
+            dl[x] = __uint_as_float(__float_as_uint(e) & updm[x]);          // e where the row moves, +0.0 elsewhere
         }
         W_PIN(dl[0]); W_PIN(dl[1]);
     };
     auto book_c = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            alpha[x] = seen[x] ? __builtin_amdgcn_exp2f(-dl[x]) : 0.f;          // 1 exactly when the row stays; (l, O are still 0 for a row without a key)
+            // 1 exactly when the row stays; 0 for a row that has not seen a key yet (its l, O are still 0)
+            alpha[x] = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(-dl[x])) & seenm[x]);
             nm[x] -= dl[x];
         }
         W_PIN(alpha[0]); W_PIN(alpha[1]); W_PIN(nm[0]); W_PIN(nm[1]);
     };
     auto book_d = [&]() __attribute__((always_inline)) {
-        if constexpr (PRE) { seen[0] = seen[0] || got[0]; seen[1] = seen[1] || got[1]; }
-        else { seen[0] = seen[0] || updv[0]; seen[1] = seen[1] || updv[1]; }
-        upd_any = __any(updv[0] || updv[1]);
+        if constexpr (PRE) { seenm[0] |= gotm[0]; seenm[1] |= gotm[1]; }
+        else { seenm[0] |= updm[0]; seenm[1] |= updm[1]; }
+        upd_any = __builtin_amdgcn_ballot_w64((updm[0] | updm[1]) != 0u) != 0ull;     // one v_cmp into an SGPR pair + a scalar compare
         resc = upd_any;
-        if constexpr (PRE) any_nm = any_nm || upd_any;
+        if constexpr (PRE) any_nm = any_nm | upd_any;
     };
     // side work of P.V gap j: 120 instructions spread at <= 4 per gap; the second-half score tuples (last written by the MFMAs of
     // phase-1 gaps 30 / 31) are first read in gap 8
@@ -506,18 +524,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         } else if (j < 16) {                        // ... of the second-half tuples
             if constexpr (!PRE) { fma_op(1, 4 * (j - 8)); fma_op(1, 4 * (j - 8) + 1); fma_op(1, 4 * (j - 8) + 2); fma_op(1, 4 * (j - 8) + 3); }
         } else if (j < 24) {                        // row max: 16 steps per query block
+#ifndef W_ABL_NOMAX
             max_op(4 * (j - 16)); max_op(4 * (j - 16) + 1); max_op(4 * (j - 16) + 2); max_op(4 * (j - 16) + 3);
+#endif
+#ifndef W_ABL_NOBOOK
         } else if (j == 24) { book_a();
         } else if (j == 25) { book_b();
         } else if (j == 26) { book_c();
         } else if (j == 27) { book_d();
+#endif
         } else if (j == 28) {
+#ifndef W_ABL_NOBOOK
             if (upd_any) {                          // rare (deferred max): re-base the exponents of the rows that moved
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
                     for (int r = 0; r < 32; ++r) W_EL(x, r) -= dl[x];
             }
+#endif
         }
     };
     auto mask_tile = [&](const int tile) __attribute__((always_inline)) {                                      // diagonal / ragged tiles only: S = -inf beyond the row's limit
@@ -628,6 +652,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #define W_M0P(SLOT_LDS, PC) asm volatile("s_add_u32 m0, %0, %1" ::"s"(SLOT_LDS), "s"(pc_off[PC]) : "memory", "m0", "scc")
 #define W_PIN_S(X) asm volatile("" ::"s"(X))
 
+#if W_PROFILE
+    uint64_t tp_[6] = {0, 0, 0, 0, 0, 0}, tl_ = __builtin_readcyclecounter();
+#endif
     for (int tile = 0; tile < n_tiles; ++tile) {
         if (resc) {                                        // rare (deferred max): some row moved its reference point for this tile
             W_NOP24();
@@ -646,6 +673,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             W_NOP24();
         }
 
+        W_STAMP(0);
         // ---- phase 1: 32 x { QK^T(tile+1) MFMA | second-half K fragment reads | exp stream of tile | DMA pieces | first V^T fragments } ---
         w_u32x4 vfr[W_VD + 1] = {};                        // V^T fragments in flight (fragment p = (16-key group p >> 2, d tile p & 3))
         w_static_for<32>([&](auto ic) __attribute__((always_inline)) {
@@ -701,6 +729,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
+        W_STAMP(1);
 #if !W_LSUM_MFMA
 #pragma unroll
         for (int x = 0; x < 2; ++x) l_run[x] = fmaf(l_run[x], alpha[x], psa[x] + psb[x]);
@@ -712,6 +741,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
 
+        W_STAMP(2);
         // ---- phase 2: 32 x { P.V(tile) MFMA | V^T fragment reads | side stream on S | first-half K(tile+2) | the next trip's setup } ------
         uint32_t kb2 = 0, vb_n[4] = {0, 0, 0, 0}, kslot_n = 0, vslot_n = 0;
         int v_idx_n = 0;
@@ -753,6 +783,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             if (j == 29) { mask_nxt_n = tile + 2 >= mask_from; }
             __builtin_amdgcn_sched_barrier(0);
         });
+        W_STAMP(3);
         kb = kb2; v_idx = v_idx_n; ksrd = ksrd_n; vsrd = vsrd_n; kslot = kslot_n; vslot = vslot_n; mask_nxt = mask_nxt_n;
 #pragma unroll
         for (int g = 0; g < 4; ++g) vb[g] = vb_n[g];
@@ -762,9 +793,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
 #ifndef W_ABL_NODMA
         W_WAIT(1);
 #endif
+        W_STAMP(4);
 #ifndef W_ABL_NOBAR
         W_BARRIER();
 #endif
+        W_STAMP(5);
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing (empty) DMA pieces: nothing may land after exit
@@ -799,6 +832,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             }
         }
     }
+#if W_PROFILE
+    if (lane == 0) {                                        // 8 floats per wave at o + 32 B * (4 * workgroup + wave): a timing build, it overwrites outputs
+        float* dbg = (float*)a.o + 8 * (4 * (int64_t)blockIdx.x + wave);
+        for (int k = 0; k < 6; ++k) dbg[k] = (float)tp_[k];
+        dbg[6] = (float)n_tiles;
+        dbg[7] = (float)qblk;
+    }
+#endif
 }
 
 // V [B, Tk, H, 128] (strided rows) -> V^T [B][H][128][vt_row] (vt_row = Tk rounded up to 64, the pad keys zero): one workgroup per

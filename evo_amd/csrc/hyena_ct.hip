@@ -227,7 +227,14 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
         // BLOCKED y (round 4): a group's 16 channels of 128 consecutive rows are 4 KiB: a store covers 8 whole lines.
         const uint32_t R = (uint32_t)(a.y_row0 + (int64_t)c.b * Ti + t0 + row);  // row of the [rows, D] matrix
         const uint32_t yb = ((R / HT_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HT_YBLK * 32) + (R % HT_YBLK) * 32 + (lane & 1) * 16;
-        const uint32_t off = !(v.st && (full || t0 + row < Ti)) ? 0xfffffff0u : (a.y_blk ? yb : row0 + (uint32_t)row * yrb + (lane & 1) * 16);
+        // (the in-range offset is computed by EVERY lane and pinned before the select: left to itself hipcc wraps the ten address instructions in an
+        //  s_and_saveexec / s_or exec region for the lanes in range -- six EXEC writes per tile in the middle of the MFMA stream, each of which
+        //  waits for the matrix pipe to drain; round 6)
+        uint32_t in_range = a.y_blk ? yb : row0 + (uint32_t)row * yrb + (lane & 1) * 16;
+#ifndef HT_OLD_SELECT                   /* A/B knob: the round-5 form (EXEC regions) */
+        asm volatile("" : "+v"(in_range));
+#endif
+        const uint32_t off = (v.st && (full || t0 + row < Ti)) ? in_range : 0xfffffff0u;
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v.sdat[hs]), "v"(off), "s"(ysrd) : "memory");
     };
 

@@ -6,6 +6,7 @@ import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from evo_amd.ops import default_ops
+from bench import TelemetrySampler                            # sclk / power of THIS GPU from its hwmon files while the launches run
 ops = default_ops(); dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 scale = float(os.environ.get("ATTN_BENCH_SCALE", "1.0"))       # 2.5: scores with the spread of the model's block 8
@@ -21,11 +22,14 @@ for (B, T) in ((8, 8193), (1, 131073)):
             for _ in range(2):
                 o = ops.attention(qx, k, v, 0, **kw)
             ts = []
-            for _ in range(5):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); o = ops.attention(qx, k, v, 0, **kw); b.record(); torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b))
+            with TelemetrySampler(0, period=0.01) as tel:
+                for _ in range(5 if T > 100000 else 40):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); o = ops.attention(qx, k, v, 0, **kw); b.record(); torch.cuda.synchronize()
+                    ts.append(a.elapsed_time(b))
             ts.sort()
+            tl = tel.summary()
+            ts = [ts[0], ts[len(ts) // 4], ts[len(ts) // 2]]
             fl = B * 4 * 4096 * T * T / 2
             rows = torch.tensor([0, 1, 255, 256, 257, T // 2, T - 2, T - 1], device=dev)
             worst = 0.0
@@ -38,4 +42,5 @@ for (B, T) in ((8, 8193), (1, 131073)):
             o2 = ops.attention(qx, k, v, 0, **kw)
             print(f"{os.environ.get('EVO_AMD_LIBNAME', 'default')}{' PRE  ' if pre else ' plain'} rep{rep}: B={B} T={T} x{scale:g}: median {ts[2]:.3f} ms (min {ts[0]:.3f}) = "
                   f"{fl / ts[2] / 1e9:.0f} TFLOP/s = {fl / ts[2] / 1e9 / 2500:.3f} of 2.5 PFLOP/s | rows vs fp32 eager rel-L2 {worst:.2e}, "
-                  f"bit-reproducible {bool(torch.equal(o, o2))}", flush=True)
+                  f"bit-reproducible {bool(torch.equal(o, o2))} | sclk {tl.get('sclk_MHz_mean', 0):.0f} MHz, {tl.get('power_W_mean', 0):.0f} W of {tl.get('power_cap_W', 0):.0f} "
+                  f"({tl.get('samples', 0)} samples)", flush=True)
