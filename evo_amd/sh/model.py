@@ -689,6 +689,40 @@ class StripedHyena(nn.Module):
         return None
 
     # ------------------------------------------------------------------ forward
+    max_rows_per_pass = 160 * 1024     # rows (B T) of one stateless pass; larger batches run in row groups (hidden_states)
+
+    def _row_groups(self, B: int, T: int):
+        """How a stateless pass over B rows of T tokens is run: [B] (one pass) or the sizes of the row groups run one after the other.
+        Batch rows are independent and every launch is row-independent, so grouping changes no row's arithmetic except through which
+        rows fall beyond a multiple of 256 (they take the weight-streaming launches).  Two reasons to group:
+        (1) more rows than `max_rows_per_pass`: the persistent dense layers address their operands with 32-bit offsets (4 GiB: z^T at
+            174 k positions, l3's input at 195 k rows); beyond that a pass would leave them for the library / three-launch routing --
+            e.g. scripts/score.py's default batch of 32 sequences at 8 k nt;
+        (2) a pass of >= 64 k rows whose rows beyond a multiple of 256 do not fit the fused single-token launches (> 8 rows, e.g.
+            16 x 8,193): its norms and gates would run unfused.
+        Groups are balanced, as few as fit, and preferably with <= 8 such rows each, as long as every group keeps >= 32 k rows (enough
+        tiles for 256 CUs; the per-group launch overhead is ~1e-4 of its time)."""
+        cap = max(1, self.max_rows_per_pass // T)
+
+        def fits(p):
+            return (p * T) % 256 <= self.DECODE_ROWS
+
+        if B <= cap and (fits(B) or B * T < 65536):
+            return [B]
+        n0 = (B + cap - 1) // cap
+
+        def split(n):
+            q, r = divmod(B, n)
+            return [q + 1] * r + [q] * (n - r)
+
+        n = n0
+        while n <= B and (B // n) * T >= 32768:
+            g = split(n)
+            if all(fits(p) for p in set(g)):
+                return g
+            n += 1
+        return split(n0)
+
     def hidden_states(self, x: torch.Tensor, inference_params_dict=None, padding_mask=None) -> torch.Tensor:
         """ids [B,T] -> final-norm hidden states [B*T, D] (logits = hidden @ E^T)."""
         if not self._packed:
@@ -697,11 +731,22 @@ class StripedHyena(nn.Module):
             raise ValueError("input_ids must be [batch, length]")
         B, T = x.shape
         ops = self.ops
+        if padding_mask is not None and tuple(padding_mask.shape) != (B, T):
+            raise ValueError(f"padding_mask must be [batch, length] = {(B, T)}, got {tuple(padding_mask.shape)}")
+        groups = self._row_groups(B, T) if inference_params_dict is None else [B]
+        if len(groups) > 1:
+            out, b0 = None, 0
+            for nb in groups:
+                pm = None if padding_mask is None else padding_mask[b0:b0 + nb]
+                hg = self.hidden_states(x[b0:b0 + nb], None, pm)
+                if out is None:
+                    out = torch.empty(B * T, hg.shape[1], dtype=hg.dtype, device=hg.device)
+                out[b0 * T:(b0 + nb) * T] = hg
+                b0 += nb
+            return out
         h = ops.embed(x.to(self.device), self.embedding_layer.weight)             # [B*T, D]
         mask = None
         if padding_mask is not None:
-            if tuple(padding_mask.shape) != (B, T):
-                raise ValueError(f"padding_mask must be [batch, length] = {(B, T)}, got {tuple(padding_mask.shape)}")
             pm = padding_mask.to(self.device) != 0
             mask = (pm.reshape(B * T, 1).to(h.dtype), pm.to(torch.uint8).contiguous())
         mha_c = inference_params_dict["mha"] if inference_params_dict is not None else None

@@ -57,3 +57,24 @@ def test_folded_model_is_the_same_function():
     assert torch.equal(m2(ids)[0].double(), got)
     with pytest.raises(RuntimeError):
         m.load_state_dict(sd)
+
+
+def test_row_groups_of_a_stateless_pass():
+    """StripedHyena._row_groups (round 6): one pass up to `max_rows_per_pass` rows (the persistent launches' 4 GiB operands) unless a pass of
+    >= 64 k rows would leave more than 8 rows beyond a multiple of 256 (they take the fused single-token launches); balanced groups, as few
+    as fit, every group >= 32 k rows when a split is a choice."""
+    from evo_amd.sh.model import StripedHyena
+
+    class Probe:
+        max_rows_per_pass = StripedHyena.max_rows_per_pass
+        DECODE_ROWS = StripedHyena.DECODE_ROWS
+        _row_groups = StripedHyena._row_groups
+    g = Probe()._row_groups
+    assert g(8, 8193) == [8] and g(1, 131073) == [1] and g(16, 513) == [16] and g(64, 1000) == [64]      # the bench shapes and small batches: one pass
+    assert g(2, 131073) == [1, 1] and g(8, 131073) == [1] * 8                                            # beyond 4 GiB of z^T: a row at a time
+    assert g(32, 8193) == [8, 8, 8, 8] and g(22, 8193) == [8, 7, 7]                                      # scripts/score.py's default batch at 8 k nt
+    assert g(16, 8193) == [8, 8] and g(9, 8193) == [5, 4]                                                # one pass would fit but leave 16 / 9 sliver rows
+    assert g(40, 5000) == [20, 20]                                                                       # no split with <= 8 sliver rows: as few groups as fit
+    for B, T in ((32, 8193), (22, 8193), (100, 5000), (7, 70000), (3, 300000)):
+        gs = g(B, T)
+        assert sum(gs) == B and max(gs) - min(gs) <= 1 and (max(gs) * T <= Probe.max_rows_per_pass or max(gs) == 1)

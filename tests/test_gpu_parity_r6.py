@@ -142,6 +142,58 @@ def test_contractive_two_full_rows_of_the_8x8193_batch_vs_fp32_oracle(contractiv
         assert (e <= 1.1 * e_flo).all() and (e <= 3.0e-2).all(), (fold, e, e_flo)
 
 
+def test_contractive_generation_8192_prompt_greedy_decode_vs_fp32_oracle(contractive):
+    """BASELINE configs[4] on the trained-like weights (the bench's `configs4` leg is a random-weight number): the 131k yml, an 8,192-nt
+    prompt without BOS through `Generator.generate` [REF evo/generation.py:38-204] -- full-prompt prefill on the scoring kernels (exact
+    carried Hyena state, KV cache), then N greedy steps of the hipGraph-captured decode step -- against the oracle's fp32 FORWARD of
+    prompt + generated tokens (a forward over the whole sequence is what a cached decode must reproduce), its eager-bf16 forward as the
+    floor.  Judged on the N decode logit rows: rel-L2, the log-prob of the emitted tokens, and every greedy choice (where the fp32
+    oracle's own argmax differs, its margin must be inside the logits' distance -- a tie the bf16 arithmetic may break either way)."""
+    from evo_amd.generation import Generator
+    from evo_amd.tokenizer import CharLevelTokenizer
+    P, N = 8192, 96
+    m = contractive["m131"]
+    prompt = acgt_ids(1, P, seed=777)[:, 1:].to(DEV)
+    g = Generator(m, CharLevelTokenizer(512), top_k=1, top_p=1.0, temperature=1.0)
+    m.decode_graph_replays = 0
+    gen, got, _ = g.generate(device=DEV, input_ids=prompt, num_tokens=N, cached_generation=True, print_generation=False, stop_at_eos=False)
+    torch.cuda.synchronize()
+    assert gen.shape == (1, N) and got.shape == (1, N, 512) and torch.isfinite(got).all()
+    assert getattr(m, "decode_graph_replays", 0) >= N - 3, getattr(m, "decode_graph_replays", 0)
+    assert torch.equal(got.argmax(-1), gen)
+    m.ops.release_workspaces()
+    full = torch.cat([prompt, gen[:, :-1]], 1).cpu()                              # token t of the forward predicts position t + 1
+    ref = _oracle(contractive, FULL_131K, "fp32")(full)[0].float()[:, P - 1:]     # [1, N, V]: the rows that emitted gen[0 .. N - 1]
+    flo = _oracle(contractive, FULL_131K, "bf16")(full)[0].float()[:, P - 1:]
+    assert ref.shape == got.shape
+
+    def judge(x):
+        e = rel_l2_rows(x, ref).item()
+        e_dec = rel_l2_rows(x[:, 1:], ref[:, 1:]).item()                          # rows 1 .. N - 1 come out of the recurrent step
+        lp, lpr = torch.log_softmax(x.double(), -1), torch.log_softmax(ref.double(), -1)
+        idx = gen[..., None]
+        d_lp = (lp.gather(-1, idx) - lpr.gather(-1, idx)).abs().squeeze(-1)
+        agree = (x.argmax(-1) == ref.argmax(-1)).float().mean().item()
+        return e, e_dec, d_lp.mean().item(), d_lp.max().item(), agree
+    e, e_dec, dm, dx, agree = judge(got)
+    f, f_dec, fm, fx, f_agree = judge(flo)
+    s_ref = torch.log_softmax(ref.double(), -1).gather(-1, gen[..., None]).mean().item()
+    s_got = torch.log_softmax(got.double(), -1).gather(-1, gen[..., None]).mean().item()
+    print(f"[generation, contractive, 131k yml] {P}-nt prompt + {N} greedy tokens ({m.decode_graph_replays} graph replays): logits rel-L2 vs fp32 oracle "
+          f"{e:.3e} (decode rows only {e_dec:.3e}); eager-bf16 reference arithmetic {f:.3e} ({f_dec:.3e}); |delta log-prob| of the emitted tokens "
+          f"mean {dm:.2e} max {dx:.2e} (eager {fm:.2e} / {fx:.2e}); greedy choice = fp32 oracle's argmax on {agree:.3f} of the steps (eager "
+          f"{f_agree:.3f}); mean log-prob of the continuation {s_got:.6f} vs {s_ref:.6f}: rel {abs(s_got - s_ref) / abs(s_ref):.2e}")
+    assert e <= 1.1 * f and e_dec <= 1.1 * f_dec and e <= 3.0e-2, (e, e_dec, f, f_dec)
+    assert abs(s_got - s_ref) / abs(s_ref) <= PIN_SCORE
+    # every disagreement with the fp32 oracle's argmax is a near tie there: its margin over the emitted token is inside the rows' distance
+    bad = (got.argmax(-1) != ref.argmax(-1))[0].nonzero().flatten().tolist()
+    for t in bad:
+        margin = (ref[0, t].max() - ref[0, t, gen[0, t]]).item()
+        dist = (got[0, t] - ref[0, t]).abs().max().item()
+        assert margin <= 2.0 * dist, (t, margin, dist)
+    assert agree >= f_agree - 0.05, (agree, f_agree)
+
+
 # ---- (b) parameter regimes of the Hyena operator ---------------------------------------------------------------------------------------
 P_MODS = (1e-2, 0.5, 0.9, 1.0 - 1e-6, 1.0)
 R_LAWS = ("1e-2", "1", "30", "cancel")              # residue scale; "cancel": scale 30, modes in pairs that cancel to 1 %
@@ -448,3 +500,77 @@ def test_one_weight_set_fold_norms_scoring_prefill_and_decode_vs_oracle():
         m2 = m2.to(DEV)
         ids = acgt_ids(4, 2048)
         assert torch.equal(m2(ids.to(DEV))[0], m(ids.to(DEV))[0])
+
+
+# ---- batches beyond one pass's 4 GiB operands: row groups ---------------------------------------------------------------------------
+def test_row_groups_are_bitwise_the_single_pass_on_whole_tiles():
+    """StripedHyena.hidden_states runs a stateless batch of more than `max_rows_per_pass` rows as equal row groups, one after the other.
+    Batch rows are independent and every launch is row-independent and deterministic: with T a multiple of 256 (no sliver rows, so no row
+    changes kernel between the two splits) the grouped pass is the single pass bit for bit -- logits, fused log-probs, and under a padding
+    mask.  4 layers at D = 4096 (Hyena / attention / Hyena / Hyena), 4 x 512 tokens, groups of 2 x 512 (still >= 1,024 rows: both on
+    the norm-folded launches)."""
+    from evo_amd.scoring import score_logprobs_device
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.synthetic import synthetic_state_dict
+    cfgd = dict(vocab_size=512, hidden_size=4096, num_layers=4, attn_layer_idxs=[1], num_attention_heads=32)
+    m = StripedHyena(dict(cfgd))
+    m.load_state_dict(synthetic_state_dict(m, seed=11, device=DEV), strict=True)
+    m.to_bfloat16_except_poles_residues()
+    m = m.to(DEV)
+    ids = acgt_ids(4, 511).to(DEV)                                                # BOS + 511 = 512 tokens per row
+    mask = torch.ones(4, 512, dtype=torch.long, device=DEV)
+    mask[1, 400:] = 0
+    mask[3, 100:] = 0
+    with torch.inference_mode():
+        one = m(ids)[0]
+        one_lp = score_logprobs_device(m, ids)[0]
+        one_m = m(ids, padding_mask=mask)[0]
+        m.max_rows_per_pass = 1024
+        try:
+            grp = m(ids)[0]
+            grp_lp = score_logprobs_device(m, ids)[0]
+            grp_m = m(ids, padding_mask=mask)[0]
+            three = m(ids[:3])[0]                                                 # 3 rows over a 2-row limit: groups of 2 + 1 (512 rows: the sub-1,024 routing)
+        finally:
+            del m.max_rows_per_pass                                               # back to the class default
+        with pytest.raises(ValueError):
+            m(ids, padding_mask=mask[:, :100])
+    assert torch.equal(grp, one) and torch.equal(grp_lp, one_lp) and torch.equal(grp_m, one_m)
+    assert three.shape == (3, 512, 512) and torch.equal(three[:2], one[:2])
+    e = rel_l2_rows(three[2:].float(), one[2:3].float()).item()
+    print(f"[row groups] 4 x 512 in groups of 2: logits, fused log-probs and the masked pass bitwise equal to the single pass; a lone third row "
+          f"(512 rows: separate norm passes) vs the same row inside the folded pass: rel-L2 {e:.2e}")
+    assert e < 6e-2                                                               # (random weights amplify the one-rounding difference between the two norm routings)
+
+
+def test_scoring_22_x_8193_beyond_the_4gib_operands_runs_in_row_groups(full):
+    """22 sequences of 8,192 nt = 180,246 rows: z^T of one pass would be 4.4 GB, beyond the 32-bit operand offsets of the persistent
+    launches (the round-5 routing fell back to the three-launch operator and library GEMMs there; scripts/score.py's default batch is 32).
+    The engine scores it in row groups of 8 / 7 / 7 (StripedHyena._row_groups) -- the largest groups below the limit whose rows beyond a multiple of 256 still fit the
+    fused single-token launches (two groups of 11 would leave 11 such rows each and run their norms and gates unfused) -- on the same
+    launches as the 8 x 8,193 step: kernel classes asserted, log-probs bitwise those of the same sequences scored 8 / 7 / 7 at a time."""
+    from evo_amd.ops import KernelTimer
+    from evo_amd.scoring import score_logprobs_device
+    m = full["m8"]
+    assert m._row_groups(22, 8193) == [8, 7, 7] and m._row_groups(8, 8193) == [8] and m._row_groups(2, 131073) == [1, 1]
+    ids = acgt_ids(22, 8192, seed=4000).to(DEV)
+    with torch.inference_mode():
+        score_logprobs_device(m, ids[:2])                                         # warm-up (workspaces of the shape come with the first group)
+        m.ops.timer = KernelTimer()
+        t0 = time.time()
+        lp = score_logprobs_device(m, ids)[0]
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        ks = m.ops.timer.summary()
+        m.ops.timer = None
+        parts = [score_logprobs_device(m, ids[a:b])[0] for a, b in ((0, 8), (8, 15), (15, 22))]
+    ref = torch.cat(parts, 0)
+    assert lp.shape == (22, 8192) and torch.isfinite(lp).all()
+    s, s_ref = lp.double().mean(-1), ref.double().mean(-1)
+    rel = ((s - s_ref).abs() / s_ref.abs()).max().item()
+    same = (lp == ref).float().mean().item()
+    print(f"[22 x 8193 in row groups] {dt * 1e3:.0f} ms = {22 * 8192 / dt / 1e3:.1f} k nt/s (timer on); launches: "
+          f"{ {k: v[0] for k, v in ks.items()} }; score vs 8 / 7 / 7-row passes: max rel {rel:.2e}, {same:.5f} of the log-probs bitwise equal")
+    assert ks.get("hyena_mfma", (0,))[0] == 3 * 29 and "hyena_apply" not in ks and "gemm" not in ks and "gelu_gate" not in ks, ks
+    assert ks["rmsnorm"][0] == 3 * 2 and ks["rms_finalize"][0] == 3 * 64, ks
+    assert rel == 0.0 and same == 1.0
