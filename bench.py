@@ -134,7 +134,15 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
              "apply_traffic": pmc_traffic("hyena_apply_kernel", B, T)}
     if "hyena_mfma" in ksum:
         ms = ksum["hyena_mfma"][1]
+        # the bytes of the tokens THIS launch walks: with ops.hyena_tail_split the last token of every row (T = 512 k + 1) is not in it
+        # (it takes the fused single-token launch, `tail_split` below), so B * 512 k tokens x 32,768 B, not B * T
+        alg_bytes = io_live.get("mfma") or alg_bytes
         ach = alg_bytes / (ms * 1e-3) / 1e9
+        tail = None
+        if "gemv_hyena" in ksum and getattr(ops, "hyena_tail_split", False):
+            tail = {"what": "the token behind the whole tiles of every batch row: pre-norm + projections + FIR / modal step in the fused single-token "
+                            "launch of the decode path, from the operator's end state (instead of a ragged tile with one valid step)",
+                    "launches_per_layer": 1, "avg_ms": ksum["gemv_hyena"][1]}
         traffic, t_commit, t_kind = pmc_traffic("hyena_ct_kernel", B, T, with_source=True)
         return {"kernel": "hyena_ct_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -145,7 +153,7 @@ def hyena_roofline(ops, model, ksum, B, T, alg_bytes, device):
                 "y_layout": "blocked [B T / 128][D / 16][128][16] (whole cache lines per store; the output projection's dense layer gathers it)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                 "tensor_bytes_per_launch": io_live.get("mfma"),
-                "operator_frac": ach / HBM_PEAK_GBS, "modal_three_launch": three,
+                "operator_frac": ach / HBM_PEAK_GBS, "tail_split": tail, "modal_three_launch": three,
                 "note": "one launch IS the whole operator (z read once, y written once: 32,768 B per token and layer); round 1 reported "
                         "hyena_apply_kernel, one of three launches: compare frac with modal_three_launch.operator_frac of the same run"}
     achieved = alg_bytes / (ksum["hyena_apply"][1] * 1e-3) / 1e9
@@ -705,6 +713,29 @@ def main():
             out["norm_unfused"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             ops.fuse_norm = True
+            ops.timer = None
+    # ------------------------------------------------------------------ the same step with every row's last token as a ragged tile of the operator
+    if n_gpus == 1 and getattr(ops, "hyena_tail_split", False) and not args.skip_ab:
+        try:
+            ops.hyena_tail_split = False
+            with torch.inference_mode():
+                dt8 = timed(lambda: scoring_step(model, ids), 3, 1, dist_on)
+                ops.timer = KernelTimer()
+                scoring_step(model, ids)
+                torch.cuda.synchronize()
+                k8 = ops.timer.summary()
+                ops.timer = None
+            ms8 = k8.get("hyena_mfma", (0, None))[1]
+            out["hyena_tail_in_operator"] = {"value": B * nt / (dt8 / 3), "unit": "nt/s", "ms_per_step": dt8 / 3 * 1e3, "steps": 3,
+                                             "hyena_ct_avg_ms": ms8, "hyena_ct_avg_ms_headline": kernels.get("hyena_mfma", {}).get("avg_ms"),
+                                             "hyena_ct_frac_of_8TBs": None if not ms8 else B * T * (3 * D * 2 + D * 2) / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "note": "ops.hyena_tail_split = False in the same process: the token behind the 8,192 main tokens of every row as a "
+                                                     "ragged 17th tile of hyena_ct (one valid step at a full tile's issue time; its projection through the "
+                                                     "weight-streaming launch) -- the rounds 4-5 form; the headline runs it through the fused single-token launch"}
+        except Exception as e:  # noqa: BLE001
+            out["hyena_tail_in_operator"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            ops.hyena_tail_split = True
             ops.timer = None
     # ------------------------------------------------------------------ the same step with the round-2..4 attention kernel
     if n_gpus == 1 and getattr(ops, "attn_w64", False) and not args.skip_ab:

@@ -80,6 +80,7 @@ struct HtArgs {
     int64_t y_rowbytes;
     int y_blk;                                              // y is [ceil(rows / 128)][D / 16][128][16] bf16 instead of [rows][D]
     int64_t y_row0, y_rows;                                 // blocked y: row of batch row 0 / total rows of the [rows, D] matrix it stands for
+    int64_t y_pitch;                                        // rows of y between two batch rows (>= T; = T unless the caller keeps rows of its own behind a batch row's T)
 };
 
 // SO = "state only": the same walk, nothing written but the end state (stage 1 of a sequence-parallel shard; x2 is not even read).
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
     const uint32_t stg_wr = HT_OFF_STG + (32 * la + 8 * lq) * 32 + la * 16 + ch0 * 2;
     const uint64_t y64 = (uint64_t)a.y;
     const ht_u32x4 ysrd = {(uint32_t)y64, (uint32_t)(y64 >> 32) & 0xffffu,
-                           (uint32_t)((a.y_blk ? (a.y_rows + HT_YBLK - 1) / HT_YBLK * HT_YBLK : (int64_t)a.B * Ti) * a.y_rowbytes), 0x00020000u};
+                           (uint32_t)((a.y_blk ? (a.y_rows + HT_YBLK - 1) / HT_YBLK * HT_YBLK : (int64_t)(a.B - 1) * a.y_pitch + Ti) * a.y_rowbytes), 0x00020000u};
     const uint32_t yrb = (uint32_t)a.y_rowbytes;
 
     float carry[HT_CPW][4];                                  // tile-entering state: components 4 lq .. 4 lq + 3, valid in lanes la = 0
@@ -220,12 +221,12 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
         const Cur& c = v.cst;
         const int t0 = c.tile * HT_TT;
         const bool full = t0 + HT_TT <= Ti;
-        const uint32_t row0 = (uint32_t)(((int64_t)c.b * Ti + t0) * a.y_rowbytes + d0 * 2);
+        const uint32_t row0 = (uint32_t)(((int64_t)c.b * a.y_pitch + t0) * a.y_rowbytes + d0 * 2);
         const int row = HT_RW * wave + 32 * hs + (lane >> 1);
         // bounds-checked buffer store: rows past the end (and the stores of the first interval, which has no previous tile) get an
         // offset beyond num_records and are dropped, so that the VM counter sees exactly HT_NST stores per interval.
         // BLOCKED y (round 4): a group's 16 channels of 128 consecutive rows are 4 KiB: a store covers 8 whole lines.
-        const uint32_t R = (uint32_t)(a.y_row0 + (int64_t)c.b * Ti + t0 + row);  // row of the [rows, D] matrix
+        const uint32_t R = (uint32_t)(a.y_row0 + (int64_t)c.b * a.y_pitch + t0 + row);  // row of the [rows, D] matrix
         const uint32_t yb = ((R / HT_YBLK) * (uint32_t)a.n_groups + (uint32_t)cg) * (HT_YBLK * 32) + (R % HT_YBLK) * 32 + (lane & 1) * 16;
         // (the in-range offset is computed by EVERY lane and pinned before the select: left to itself hipcc wraps the ten address instructions in an
         //  s_and_saveexec / s_or exec region for the lanes in range -- six EXEC writes per tile in the middle of the MFMA stream, each of which
@@ -551,11 +552,14 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
 extern "C" int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                             const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
                             int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t tail_T, int64_t tail_pos0, int64_t state_only,
-                            int64_t y_blocked_rows, int64_t y_row0, void* stream) {
+                            int64_t y_blocked_rows, int64_t y_row0, int64_t y_row_pitch, void* stream) {
     if (B <= 0 || T <= 0 || D <= 0 || n_heads <= 0 || D != n_heads * 128) return -1;
     const int64_t yrb = D * 2;
-    if (B * T * yrb >= 0xfffffff0ll) return -1;                                      // 32-bit offsets inside y
-    if (y_blocked_rows && (y_row0 < 0 || y_row0 + B * T > y_blocked_rows || (y_blocked_rows + HT_YBLK) * yrb >= 0xfffffff0ll)) return -1;
+    if (y_row_pitch == 0) y_row_pitch = T;
+    if (y_row_pitch < T) return -1;
+    const int64_t y_span = (B - 1) * y_row_pitch + T;                                // rows of y from batch row 0's first to the last row's last
+    if (y_span * yrb >= 0xfffffff0ll) return -1;                                     // 32-bit offsets inside y
+    if (y_blocked_rows && (y_row0 < 0 || y_row0 + y_span > y_blocked_rows || (y_blocked_rows + HT_YBLK) * yrb >= 0xfffffff0ll)) return -1;
     // z^T: 16-byte loads -> every batch row starts at a multiple of 8 positions; 32-bit byte offsets inside a column
     if ((!tail_T && row_pitch < T) || row_pitch % 8 != 0 || zt_row0 < 0 || zt_row0 % 8 != 0 || zt_pitch % HT_ZBLK != 0 || zt_pitch < HT_ZBLK) return -1;
     if (zt_pitch * 3 * D * 2 >= 0xfffffff0ll) return -1;                                                    // 32-bit byte offsets inside z^T
@@ -577,7 +581,7 @@ extern "C" int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_
     a.tab = (const uint32_t*)table; a.y = (unsigned char*)y; a.s0 = s0; a.s_out = s_out; a.poles = poles;
     a.B = (int)B; a.T = (int)T; a.D = (int)D; a.n_tiles = (int)((T + HT_TT - 1) / HT_TT); a.n_groups = (int)groups;
     a.nb_split = (int)nb_split; a.zt_pitch = zt_pitch; a.row_pitch = row_pitch; a.zt_row0 = zt_row0; a.tail_T = tail_T; a.tail_pos0 = tail_pos0; a.y_rowbytes = yrb;
-    a.y_blk = y_blocked_rows ? 1 : 0; a.y_row0 = y_row0; a.y_rows = y_blocked_rows;
+    a.y_blk = y_blocked_rows ? 1 : 0; a.y_row0 = y_row0; a.y_rows = y_blocked_rows; a.y_pitch = y_row_pitch;
     if (state_only) hipLaunchKernelGGL((hyena_ct_kernel<true, true>), dim3((unsigned)streams), dim3(HT_THREADS), 0, (hipStream_t)stream, a);
     else if (s_out) hipLaunchKernelGGL((hyena_ct_kernel<false, true>), dim3((unsigned)streams), dim3(HT_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((hyena_ct_kernel<false, false>), dim3((unsigned)streams), dim3(HT_THREADS), 0, (hipStream_t)stream, a);

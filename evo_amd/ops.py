@@ -38,7 +38,7 @@ _SIGNATURES = {
     "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_mfma_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
-    "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 12 + [_PTR], _c.c_int),
+    "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 13 + [_PTR], _c.c_int),
     "evo_linear_t_mfma_bf16": ([_PTR] * 4 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_rmsnorm_rows_bf16": ([_PTR, _PTR, _PTR, _PTR, _I64, _I64, _F32, _I64, _I64, _I64, _I64, _PTR], _c.c_int),
     "evo_linear_xblk_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
@@ -180,6 +180,10 @@ class HipOps:
         # False = the separate rmsnorm launches: bench.py's A/B leg, the routing test)
         self.fuse_norm = True
         self.attn_prescale = True         # the model folds softmax_scale * log2(e) into the rotary kernel's one rounding of q; attention kernels take scores as exponents (csrc/attn_w64.hip PRE)
+        # round 6: T = 512 k + 1 scoring batches (a BOS token in front of 2^k nucleotides) run the 512 k main tokens of every row through hyena_ct in
+        # whole tiles and the one token behind them through the fused single-token launch, from the operator's end state; False: the ragged last
+        # tile (one valid step at a full tile's issue time) inside the operator, the tail tokens' projections through the weight-streaming launch
+        self.hyena_tail_split = True
         self.hyena_table_guard = True     # Hyena layers whose filter the bf16 hi / lo operand tables cannot hold run the modal kernels (hyena_tables.table_precision)
         # all_gemm_mfma = False puts the plain dense layers (l3, the unembedding of model(ids)) back on hipBLASLt through torch.addmm:
         # the library is 1-3 % faster on l3's shape (K = 11,008; profiles/r03_gemm_notes.txt) -- bench.py times that leg beside the headline
@@ -426,21 +430,22 @@ class HipOps:
                                                   _stream()), "evo_rmsnorm_rows_bf16")
         return out
 
-    def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], B: int, T: int) -> torch.Tensor:
+    def linear_t(self, xp: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], B: int, T: int, tail: bool = True) -> torch.Tensor:
         """z^T = (x @ w [N, K]^T + b)^T in blocks of 256 positions, [Mp / 256 (+ 1), N, 256] bf16, from rmsnorm_rows' buffer xp: the dense
         layer launched with swapped operands on the Mp main rows (csrc/gemm.hip, mode 3), the tail tokens (zt_layout) through the
-        weight-streaming kernel into the tail block; w in the REFERENCE's row order (no regrouped copy)."""
+        weight-streaming kernel into the tail block; w in the REFERENCE's row order (no regrouped copy).  `tail=False`: the main area
+        only (the caller takes the tail tokens through the single-token launch: hyena_ct(main_only=True))."""
         self._need(xp, torch.bfloat16, "linear_t x")
         self._need(w, torch.bfloat16, "linear_t w")
         Tm, Tp, Mp, r = self.zt_layout(B, T)
         K = xp.shape[1]
         N = w.shape[0]
         assert xp.shape[0] >= Mp + B * r
-        zt = torch.empty(Mp // 256 + (1 if r else 0), N, 256, dtype=torch.bfloat16, device=xp.device)
+        zt = torch.empty(Mp // 256 + (1 if r and tail else 0), N, 256, dtype=torch.bfloat16, device=xp.device)
         with self._t("gemm_zt"):
             _check(self.lib.evo_linear_t_mfma_bf16(xp.data_ptr(), w.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K, _stream()),
                    "evo_linear_t_mfma_bf16")
-        if r:
+        if r and tail:
             zt[-1].zero_()                                                                # (6 MB: the tail block's unused positions hold zeros, not whatever the allocator left)
             z_tail = self._linear_small_m(xp[Mp:Mp + B * r], w, b, None)                # [B r, N]
             zt[-1].view(N, 32, 8)[:, :B, :r] = z_tail.view(B, r, N).permute(2, 0, 1)      # position Mp + 8 b + j
@@ -468,19 +473,28 @@ class HipOps:
         return flat.view(C, P // 256, 256).permute(1, 0, 2).contiguous()
 
     def hyena_ct(self, zt, B, T, fir_w, fir_b, table, n_heads, z_halo=None, s0=None, want_state=False, poles=None,
-                 state_only=False, b_first=0, y_blk=None, y_row0=0, b_total=None):
+                 state_only=False, b_first=0, y_blk=None, y_row0=0, b_total=None, main_only=False):
         """The channel-stationary single-pass operator on CHANNEL-MAJOR z (csrc/hyena_ct.hip: evo_hyena_ct): zt [blocks, 3 D, 256] bf16 =
         linear_t's result (zt_layout of a [b_total, T] batch; b_total defaults to b_first + B); B batch rows of T tokens starting at
         batch row `b_first` of the tensor (a sub-range).  -> y [B,T,D] bf16 | (y, end state [B,D,8] complex64) with `want_state` | the end state alone with `state_only` (stage 1 of a
         sequence-parallel shard: nothing else is written).  `z_halo` [B, 2, 3 D] in the REFERENCE's column order, `s0` [B,D,8] complex:
         FIR history / modal state before the first token.  `y_blk` (from yblk_empty): the outputs go THERE, blocked, batch row b /
-        token t as row y_row0 + b T + t -- the form the kernel stores fastest and linear_residual_yblk_ reads."""
+        token t as row y_row0 + b T + t -- the form the kernel stores fastest and linear_residual_yblk_ reads.
+        `main_only` (tail form of zt_layout only): the operator walks the Tm = 512 k main tokens of every row -- whole tiles -- and leaves
+        rows b T + Tm .. of y untouched; with `want_state` the state returned is the one after token Tm - 1: the caller finishes the r
+        tail tokens with the single-token launch (hyena_decode_fused / hyena_step) from that state (StripedHyena._hyena_block; a ragged
+        tile with one valid step costs the kernel a full tile's issue time: 8 of 136 tile steps at 8 x 8,193)."""
         self._need(zt, torch.bfloat16, "hyena z^T")
         assert zt.dim() == 3 and zt.shape[2] == 256
         D3, P = zt.shape[1], zt.shape[0] * 256
         D = D3 // 3
         Tm, Tp, Mp, r = self.zt_layout(b_first + B if b_total is None else b_total, T)
-        assert D3 == 3 * D and P == Mp + (256 if r else 0) and (b_first + B) * Tp <= Mp
+        assert D3 == 3 * D and (b_first + B) * Tp <= Mp
+        if main_only:
+            assert r > 0 and P in (Mp, Mp + 256) and z_halo is None and s0 is None and not state_only
+        else:
+            assert P == Mp + (256 if r else 0)
+        T_run = Tm if main_only else T
         if table.dtype != torch.int32 or tuple(table.shape) != (D, 52, 64) or not table.is_contiguous() or not table.is_cuda:
             raise RuntimeError("hyena_ct: table must be the contiguous int32 [D, 52, 64] tensor of mfma_operand_table")
         for t, nm in ((fir_w, "fir_w"), (fir_b, "fir_b")):
@@ -512,12 +526,13 @@ class HipOps:
             y = torch.empty(B, T, D, dtype=torch.bfloat16, device=zt.device)
         with self._t("hyena_mfma_state" if state_only else "hyena_mfma"):
             _check(self.lib.evo_hyena_ct(zt.data_ptr(), _ptr(z_halo), fir_w.data_ptr(), fir_b.data_ptr(), table.data_ptr(), _ptr(y),
-                                         _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T, D, n_heads, P, Tp, b_first * Tp,
-                                         Tm if r else 0, Mp + 8 * b_first, 1 if state_only else 0, yb_rows, y_row0, _stream()),
+                                         _ptr(s0r), _ptr(s_fin), _ptr(poles), B, T_run, D, n_heads, P, Tp, b_first * Tp,
+                                         Tm if r and not main_only else 0, Mp + 8 * b_first, 1 if state_only else 0, yb_rows, y_row0,
+                                         T if main_only else 0, _stream()),
                    "evo_hyena_ct")
         if state_only:
             return torch.view_as_complex(s_fin)
-        self.last_hyena_io = {"mfma": B * T * 3 * D * 2 + B * T * D * 2}
+        self.last_hyena_io = {"mfma": B * T_run * 3 * D * 2 + B * T_run * D * 2}
         return (y, torch.view_as_complex(s_fin)) if want_state else y
 
     def hyena_prefill(self, z: torch.Tensor, fir_w: torch.Tensor, fir_b: torch.Tensor, poles: torch.Tensor,
@@ -701,7 +716,7 @@ class HipOps:
         return Tp == T and Mp == B * T
 
     def linear_t_rs(self, x: torch.Tensor, rstd: torch.Tensor, w_folded: torch.Tensor, b: Optional[torch.Tensor], w: torch.Tensor,
-                    scale: torch.Tensor, eps: float, B: int, T: int) -> torch.Tensor:
+                    scale: torch.Tensor, eps: float, B: int, T: int, tail: bool = True) -> torch.Tensor:
         """linear_t(rmsnorm_rows(x), w, b) without the normalised copy, for the layouts of zt_stream_rows_ok: the swapped-operand dense layer
         reads the raw stream x [B T, K] and scales by rstd in its epilogue; in the tail form the B r tail tokens take the norm-folding
         weight-streaming launch on w itself."""
@@ -715,10 +730,12 @@ class HipOps:
                 _check(self.lib.evo_linear_t_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w_folded.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K,
                                                           Mp, Mp, 0, _stream()), "evo_linear_t_mfma_nf_bf16")
             return zt
-        zt = torch.empty(Mp // 256 + 1, N, 256, dtype=torch.bfloat16, device=x.device)
+        zt = torch.empty(Mp // 256 + (1 if tail else 0), N, 256, dtype=torch.bfloat16, device=x.device)
         with self._t("gemm_zt"):
             _check(self.lib.evo_linear_t_mfma_nf_bf16(x.data_ptr(), rstd.data_ptr(), w_folded.data_ptr(), _ptr(b), zt.data_ptr(), Mp, N, K,
                                                       B * T, Tm, r, _stream()), "evo_linear_t_mfma_nf_bf16")
+        if not tail:                                  # (the caller runs the tail tokens through the single-token launch: hyena_ct(main_only=True))
+            return zt
         zt[-1].zero_()
         x_tail = x.view(B, T, K)[:, Tm:].reshape(B * r, K).contiguous()                           # (a copy of B r <= 16 rows)
         z_tail = self.norm_linear(x_tail, scale, eps, w, b)                             # [B r, N]

@@ -572,15 +572,30 @@ class StripedHyena(nn.Module):
             table = self._mfma_table(blk)
             nf = self._nf_ok(B * T, mask)
             pb = None if blk.projections.bias is None else blk.projections.bias.data
+            # T = 512 k + 1 (a BOS token in front of 2^k nucleotides), scoring: the one token behind the whole tiles of every row does not
+            # go through the operator as a ragged tile (one valid step at a full tile's issue time: 8 of 136 tile steps at 8 x 8,193) but
+            # through the fused single-token launch of the decode path, from the operator's end state (ops.hyena_tail_split)
+            Tm, _, _, r_tail = ops.zt_layout(B, T)
+            split = (cache is None and r_tail == 1 and getattr(ops, "hyena_tail_split", False) and B <= self.DECODE_ROWS
+                     and (B <= 4 or D == 4096) and pb is not None)
             if nf and rs is not None and ops.zt_stream_rows_ok(B, T):
                 # pre-norm folded: the projection reads the stream itself (z^T layouts without pad positions inside the main area: no padded copy either)
                 wp_f = self._folded(blk, "_wp_f", blk.projections.weight, blk.pre_norm.scale)
-                zt = ops.linear_t_rs(x2d, rs, wp_f, pb, blk.projections.weight.data, blk.pre_norm.scale, self.eps, B, T)
+                zt = ops.linear_t_rs(x2d, rs, wp_f, pb, blk.projections.weight.data, blk.pre_norm.scale, self.eps, B, T, tail=not split)
             else:
                 xp = ops.rmsnorm_rows(x2d, blk.pre_norm.scale, self.eps, B, T)
-                zt = ops.linear_t(xp, blk.projections.weight.data, pb, B, T)
+                zt = ops.linear_t(xp, blk.projections.weight.data, pb, B, T, tail=not split)
             yb = ops.yblk_empty(B * T, D, zt.device)
-            if cache is None:
+            if split:
+                y, state = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, want_state=True, poles=f._poles, y_blk=yb,
+                                        main_only=True)
+                ix = self._tail_split_index(B, T, zt.device)
+                fir = zt[ix["zblk"], :, 256 - K1:].contiguous()                         # [B, 3 D, 2]: steps Tm - 2, Tm - 1 of every row, oldest first
+                x_tail = x2d.view(B, T, D)[:, Tm].contiguous()                          # the raw stream's rows (the launch norms them itself)
+                y_tail = ops.hyena_decode_fused(x_tail, blk.pre_norm.scale, self.eps, blk.projections.weight, blk.projections.bias, fir, state,
+                                                f._fir_w, f.short_filter_bias, f._poles, f._residues, f.D, H)
+                yb[ix["yblk"], :, ix["yrow"], :] = y_tail.view(B, D // 16, 16)          # rows b T + Tm of the blocked y
+            elif cache is None:
                 y = ops.hyena_ct(zt, B, T, f._fir_w, f.short_filter_bias, table, H, y_blk=yb)
             else:
                 halo = s0 = None
@@ -619,6 +634,19 @@ class StripedHyena(nn.Module):
         self._mlp_residual_(blk, x2d, self._mixer_out_(blk, x2d, y, blk.out_filter_dense.weight, blk.out_filter_dense.bias),
                             None if mask is None else mask[0])
         return None
+
+    def _tail_split_index(self, B: int, T: int, device):
+        """Index tensors of the tail-split routing (_hyena_block), cached per (B, T): the z^T block holding the last two main steps of every
+        batch row, and block / row of the blocked y for the rows b T + Tm."""
+        key = (B, T, str(device))
+        cur = getattr(self, "_tail_ix", None)
+        if cur is None or cur[0] != key:
+            Tm = self.ops.zt_layout(B, T)[0]
+            b = torch.arange(B, device=device)
+            R = b * T + Tm
+            cur = (key, {"zblk": (b * Tm + Tm - 1) // 256, "yblk": R // self.ops.YBLK, "yrow": R % self.ops.YBLK})
+            self._tail_ix = cur
+        return cur[1]
 
     def _kv_buffer(self, cache: InferenceParams, i: int, B: int, need: int, like: torch.Tensor):
         H, hd = self.num_heads, self.head_dim

@@ -46,7 +46,8 @@ extern "C" {
  *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set);
  *      evo_rope_qk_bf16 and evo_rope_append_decode_bf16 gained `q_scale`, evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 accept
  *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply); evo_linear_small_m_bf16
- *      takes up to 64 rows. */
+ *      takes up to 64 rows; evo_hyena_ct gained `y_row_pitch` (rows of y between two batch rows: the scoring path runs the 512 k main tokens
+ *      of every row through the operator and the one token behind them through the single-token launch, see below). */
 #define EVO_ABI_VERSION 10
 int evo_abi_version(void);
 
@@ -134,13 +135,17 @@ int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const 
  *          goes to the other ranks before anybody can finish its outputs (new; the reference has no multi-GPU path)
  *   y      [B, T, D] bf16, or with y_blocked_rows != 0 BLOCKED: [ceil(y_blocked_rows / 128)][D / 16][128][16] bf16 -- the
  *          [y_blocked_rows, D] matrix with a group's 16 channels of 128 consecutive rows kept together (whole cache lines per
- *          store; evo_linear_xblk_mfma_bf16 reads it); batch row b, token t is row y_row0 + b T + t of that matrix (y_row0 > 0:
+ *          store; evo_linear_xblk_mfma_bf16 reads it); batch row b, token t is row y_row0 + b y_row_pitch + t of that matrix (y_row0 > 0:
  *          the row groups of a sequence-parallel shard write into one tensor)
+ *   y_row_pitch (ABI 10): rows of y between two batch rows, 0 = T.  > T: the caller owns rows T .. y_row_pitch - 1 behind every batch
+ *          row (T = 512 k + 1 scoring batches: the operator walks the 512 k tokens in whole tiles and returns s_out, the last token of every
+ *          row is one evo_hyena_decode_fused_small_m step from that state -- a ragged tile with ONE valid step costs a full tile's issue
+ *          time, 8 of 136 tile steps at 8 x 8,193)
  *   no mask (padding_mask shapes take the three-launch form).  D == n_heads * 128. */
 int evo_hyena_ct(const void* zt, const void* z_halo, const void* fir_w, const void* fir_b, const void* table, void* y,
                  const float* s0, float* s_out, const float* poles, int64_t B, int64_t T, int64_t D, int64_t n_heads,
                  int64_t zt_pitch, int64_t row_pitch, int64_t zt_row0, int64_t tail_T, int64_t tail_pos0, int64_t state_only,
-                 int64_t y_blocked_rows, int64_t y_row0, void* stream);
+                 int64_t y_blocked_rows, int64_t y_row0, int64_t y_row_pitch, void* stream);
 
 /* The Hyena block's output projection on the blocked y of evo_hyena_ct               [REF stripedhyena/model.py ParallelGatedConvBlock:
  * out_filter_dense]:  y [M, N] = x . w^T (+ bias [N]) (+ residual [M, N], may alias y), x = [M / 128][K / 16][128][16] bf16.  The persistent dense

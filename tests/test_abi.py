@@ -54,15 +54,16 @@ def test_argument_validation_needs_no_gpu():
     assert lib.evo_mlp_gate_mfma_bf16(None, None, None, 256, 100, 128, None) == -1                   # (2 I) % 256
     assert lib.evo_mlp_gate_mfma_bf16(None, None, None, 256, 128, 96, None) == -1                    # K % 64
     one = ctypes.c_void_p(16)                                                                       # (a non-null, 16-byte aligned pointer value: never dereferenced)
-    # evo_hyena_ct(..., B, T, D, H, zt_pitch, row_pitch, zt_row0, tail_T, tail_pos0, state_only, y_blocked_rows, y_row0, stream)
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 100, 0, 0, 0, 0, 0, 0, None) == -1   # row pitch % 8
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 200, 104, 0, 0, 0, 0, 0, 0, None) == -1   # z^T not whole 256-position blocks
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 3, 100, 256, 2, 256, 104, 0, 0, 0, 0, 0, 0, None) == -1   # rows beyond z^T
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 104, 4, 0, 0, 0, 0, 0, None) == -1   # first position % 8
-    assert lib.evo_hyena_ct(one, None, None, None, None, None, None, None, None, 2, 100, 256, 2, 256, 104, 0, 0, 0, 1, 0, 0, None) == -1  # state-only without s_out
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 500, 1024, 0, 0, 0, None) == -1   # tail_T % 512
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 530, 256, 2, 1280, 512, 0, 512, 1024, 0, 0, 0, None) == -1   # more than 8 tail tokens
-    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 512, 1000, 0, 0, 0, None) == -1   # tail block inside the main area
+    # evo_hyena_ct(..., B, T, D, H, zt_pitch, row_pitch, zt_row0, tail_T, tail_pos0, state_only, y_blocked_rows, y_row0, y_row_pitch, stream)
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 100, 0, 0, 0, 0, 0, 0, 0, None) == -1   # row pitch % 8
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 200, 104, 0, 0, 0, 0, 0, 0, 0, None) == -1   # z^T not whole 256-position blocks
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 3, 100, 256, 2, 256, 104, 0, 0, 0, 0, 0, 0, 0, None) == -1   # rows beyond z^T
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 100, 256, 2, 256, 104, 4, 0, 0, 0, 0, 0, 0, None) == -1   # first position % 8
+    assert lib.evo_hyena_ct(one, None, None, None, None, None, None, None, None, 2, 100, 256, 2, 256, 104, 0, 0, 0, 1, 0, 0, 0, None) == -1  # state-only without s_out
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 500, 1024, 0, 0, 0, 0, None) == -1   # tail_T % 512
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 530, 256, 2, 1280, 512, 0, 512, 1024, 0, 0, 0, 0, None) == -1   # more than 8 tail tokens
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 513, 256, 2, 1280, 512, 0, 512, 1000, 0, 0, 0, 0, None) == -1   # tail block inside the main area
+    assert lib.evo_hyena_ct(one, None, None, None, None, one, None, None, None, 2, 104, 256, 2, 256, 104, 0, 0, 0, 0, 0, 0, 100, None) == -1   # y_row_pitch below T
     assert lib.evo_linear_t_mfma_bf16(None, None, None, None, 300, 768, 256, None) == -1              # Mp % 256
     assert lib.evo_linear_t_mfma_bf16(None, None, None, None, 512, 700, 256, None) == -1              # N % 256
     assert lib.evo_rmsnorm_rows_bf16(None, None, None, None, 200, 64, 1e-6, 100, 96, 100, 0, None) == -1      # pitch < Tm

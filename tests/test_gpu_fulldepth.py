@@ -174,7 +174,7 @@ def test_full_depth_7b_configs0_vs_fp32_oracle(full, name):
     assert err <= floor                                       # never further from fp32 than eager bf16 is
 
 
-@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "attention_round4", "modal_hyena", "norm_unfused"])
+@pytest.mark.parametrize("gemm", ["default", "library_l3", "unfused", "attention_round4", "modal_hyena", "norm_unfused", "tail_in_operator"])
 def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     """(b) BASELINE configs[1]: the 8 x 8,193 scoring batch on the HIP engine; row 3's first 2,049 positions vs the fp32
     oracle run on that prefix alone (the model is causal) -- end to end, and block by block with the engine's own
@@ -185,13 +185,15 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     A/B routings bench.py times beside the headline: `library_l3` (ops.all_gemm_mfma = False: l3 / unembedding on hipBLASLt),
     `unfused` (dense layer + gate kernel), `attention_round4` (ops.attn_w64 = False: the 8-wave attention kernel of rounds 2-4) and
     `modal_hyena` (ops.hyena_mfma = False: the three-launch modal Hyena kernels on token-major z), `norm_unfused` (ops.fuse_norm = False:
-    the 65 separate RMSNorm passes of rounds 1-4 instead of the norm folded into the dense layers' epilogues)."""
+    the 65 separate RMSNorm passes of rounds 1-4 instead of the norm folded into the dense layers' epilogues), `tail_in_operator`
+    (ops.hyena_tail_split = False: the last token of every row as a ragged tile of hyena_ct instead of one fused single-token launch)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P, row = 2049, 3
     ids = acgt_ids(8, 8192)
     m = full["m8"]
     ops = m.ops
     was = ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma, ops.fuse_norm
+    was_split, ops.hyena_tail_split = ops.hyena_tail_split, gemm != "tail_in_operator"
     ops.all_gemm_mfma = gemm != "library_l3"
     ops.mlp_gate_fused = gemm != "unfused"
     ops.attn_w64 = gemm != "attention_round4"
@@ -210,6 +212,7 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     finally:
         m.block_taps = None
         ops.all_gemm_mfma, ops.mlp_gate_fused, ops.attn_w64, ops.hyena_mfma, ops.fuse_norm = was
+        ops.hyena_tail_split = was_split
         ops.timer = None
     # the routing under test really ran (here `model(ids)` materialises logits through ops.linear: one more dense layer than a
     # scoring step, whose unembedding is fused into the tail kernel)
@@ -219,10 +222,12 @@ def test_prefix_of_bench_batch_vs_fp32_oracle(full, gemm):
     else:
         assert launches.get("gemm_zt", 0) == 29 and launches.get("hyena_mfma", 0) == 29 and launches.get("hyena_apply", 0) == 0
     assert launches.get("attn_fwd", 0) == 3
+    # the token behind the 8,192 main tokens of every row: one fused single-token launch per Hyena layer (default), or inside the operator
+    assert launches.get("gemv_hyena", 0) == (0 if gemm in ("tail_in_operator", "modal_hyena") else 29), launches
     # the RMSNorm passes: folded into the dense layers on the default routing (what is left: block 0's pre-norm and the final norm);
     # the folding needs the hand-written dense layer everywhere and the gated launch, the modal Hyena path norms for itself
     n_norm = launches.get("rmsnorm", 0)
-    if gemm in ("default", "attention_round4"):
+    if gemm in ("default", "attention_round4", "tail_in_operator"):
         assert n_norm == 2 and launches.get("rms_finalize", 0) == 64, launches
     elif gemm == "modal_hyena":                            # (the modal Hyena path norms for itself; only the attention blocks' MLPs fold)
         assert n_norm == 62 and launches.get("rms_finalize", 0) == 6, launches
@@ -305,10 +310,22 @@ def _check_hyena_fullsize(B, T, seed, state_tol, form):
     Tm, Tp, Mp, r = ops.zt_layout(B, T)
     assert (r > 0) == (form == "tail"), (form, Tm, Tp, Mp, r)               # the shape takes the form of z^T it is meant to test
     assert ops.zt_shape_ok(B, T, 3 * D, D)                                    # ... and the model routes it to hyena_ct (sh/model.py:_hyena_ct_ok)
-    for path in ("modal", "hyena_ct"):
+    # round 6: T = 512 k + 1 -- what the scoring path launches since then (ops.hyena_tail_split): the operator on the 512 k main tokens of
+    # every row (whole tiles, y rows at a pitch of T), the token behind them as ONE step of the decode kernel from the operator's end state
+    for path in ("modal", "hyena_ct") + (("hyena_ct main + step",) if r == 1 else ()):
         if path == "modal":
             y, st = ops.hyena_prefill(z, *prm, want_state=True)
             assert "apply" in ops.last_hyena_io
+        elif path == "hyena_ct main + step":
+            zt = ops.zt_from_rows(z, B, T, pad_value=float("nan"))
+            yb = ops.yblk_empty(B * T, D, z.device)
+            yb.fill_(float("nan"))
+            yb, st = ops.hyena_ct(zt, B, T, fir_w, fir_b, table, H, want_state=True, poles=poles, y_blk=yb, main_only=True)
+            y = ops.yblk_to_rows(yb, B * T).view(B, T, D).clone()
+            assert torch.isnan(y[:, Tm:]).all() and torch.isfinite(y[:, :Tm]).all()      # the rows behind the main tokens are the caller's
+            fir = z[:, Tm - 2:Tm].transpose(1, 2).contiguous()                            # [B, 3 D, 2], oldest first
+            y[:, Tm] = ops.hyena_step(z[:, Tm].contiguous(), fir, st, fir_w, fir_b, poles, res, dskip, H)   # (st updated in place: the state after T - 1)
+            del zt, yb
         else:
             zt = ops.zt_from_rows(z, B, T, pad_value=float("nan"))
             yb, st = ops.hyena_ct(zt, B, T, fir_w, fir_b, table, H, want_state=True, poles=poles, y_blk=ops.yblk_empty(B * T, D, z.device))

@@ -290,30 +290,30 @@ def test_configs3_eight_virtual_ranks_16385_token_shards_d4096():
     assert lp.shape == want.shape
     dlp, dscore = (lp - want).abs().mean().item(), (abs(lp.mean() - want.mean()) / abs(want.mean())).item()
     # the yardstick at THESE dimensions: the unsharded forward once more with the Hyena operator on its OTHER kernels.  The 2 x 131,073
-    # batch above is outside hyena_ct's 32-bit contract (6.4 GB of z^T) and ran the modal three-launch form; row by row (3.2 GB each) the
-    # same forward runs hyena_ct -- the same operator to fp32 rounding, i.e. a few per cent of the bf16 outputs of every Hyena layer land
-    # on the other side of a rounding boundary: exactly the perturbation a carried-in state is.  What it grows to through the remaining
-    # layers is "bf16 noise of another evaluation order" at D = 4096 (the toy models of the two-process test: 4.5e-3).
-    launched = {}
-    real = ops.hyena_ct
-
-    def count_ct(*a_, **k_):
-        launched["ct"] = launched.get("ct", 0) + 1
-        return real(*a_, **k_)
-
-    ops.hyena_ct = count_ct
+    # batch above runs a row at a time on hyena_ct (round 6: StripedHyena._row_groups -- one pass would be 6.4 GB of z^T, outside the 32-bit
+    # contract); the same forward on the modal three-launch form (ops.hyena_mfma = False) is the same operator to fp32 rounding, i.e. a few
+    # per cent of the bf16 outputs of every Hyena layer land on the other side of a rounding boundary: exactly the perturbation a carried-in
+    # state is.  What it grows to through the remaining layers is "bf16 noise of another evaluation order" at D = 4096 (the toy models of
+    # the two-process test: 4.5e-3).
+    assert m._row_groups(B, T) == [1] * B
+    from evo_amd.ops import KernelTimer
+    was_mfma, ops.hyena_mfma = ops.hyena_mfma, False
+    ops.timer = KernelTimer()
     try:
         with torch.inference_mode():
-            other = torch.cat([m(ids[b:b + 1])[0] for b in range(B)], 0)
+            other = m(ids)[0]
+        torch.cuda.synchronize()
+        launched = {k: v[0] for k, v in ops.timer.summary().items()}
     finally:
-        del ops.hyena_ct
-    assert launched.get("ct", 0) == 3 * B                      # (3 Hyena layers per row: the yardstick really is the other kernel)
+        ops.hyena_mfma = was_mfma
+        ops.timer = None
+    assert launched.get("hyena_apply", 0) == 3 * B and launched.get("hyena_mfma", 0) == 0, launched      # (3 Hyena layers per row: the yardstick really is the other kernel)
     noise = rel_l2(other, full_logits)
     noise_shards = [rel_l2(other[:, o[0][1]:o[0][2]], full_logits[:, o[0][1]:o[0][2]]) for o in outs]
     del other
     print(f"[configs3, 8 virtual ranks x 16,385 tokens, D = 4096, 4 layers] sharded vs unsharded HIP forward: logits rel-L2 {err:.3e} "
           f"(per shard {' '.join(f'{x:.2e}' for x in per_shard)}), mean |d logprob| {dlp:.2e}, score rel {dscore:.2e}; "
-          f"evaluation-order yardstick (the same forward row by row on hyena_ct vs the batch on the modal kernels): {noise:.3e} (per shard {' '.join(f'{x:.2e}' for x in noise_shards)})")
+          f"evaluation-order yardstick (the same forward on the modal three-launch kernels vs on hyena_ct): {noise:.3e} (per shard {' '.join(f'{x:.2e}' for x in noise_shards)})")
     # shard 0 has no carry-in and no halo and sees only its own keys: (almost) the unsharded arithmetic; the other shards add the
     # fp32 carry / pole-power arithmetic, which must not show beyond the yardstick
     sharded_ok = err <= max(1.5 * noise, 8e-3) and max(per_shard) <= max(1.5 * max(noise_shards), 1.2e-2)

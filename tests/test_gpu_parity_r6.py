@@ -574,3 +574,50 @@ def test_scoring_22_x_8193_beyond_the_4gib_operands_runs_in_row_groups(full):
     assert ks.get("hyena_mfma", (0,))[0] == 3 * 29 and "hyena_apply" not in ks and "gemm" not in ks and "gelu_gate" not in ks, ks
     assert ks["rmsnorm"][0] == 3 * 2 and ks["rms_finalize"][0] == 3 * 64, ks
     assert rel == 0.0 and same == 1.0
+
+
+# ---- the token behind the whole tiles of a row: single-token launch instead of a ragged tile -----------------------------------------
+def test_tail_token_through_the_single_token_launch_vs_the_ragged_tile_and_the_oracle():
+    """ops.hyena_tail_split (round 6, default): for T = 512 k + 1 the Hyena operator walks the 512 k main tokens of every row in whole tiles
+    and the token behind them takes the decode path's fused launch (pre-norm + projections + FIR / modal step) from the operator's end
+    state; before, it was a ragged tile of hyena_ct (one valid step at a full tile's issue time).  4 layers at D = 4096 (Hyena / attention /
+    Hyena / Hyena), 4 x 1,025 tokens (norm-folded routing) and 1 x 513 (separate norm passes): the main rows' logits are bit-identical in
+    both routings (nothing of them changed); the last row of every sequence is judged against the fp32 oracle beside the ragged-tile
+    routing and the eager-bf16 floor.  Launch counts asserted."""
+    from evo_amd.ops import KernelTimer
+    from evo_amd.sh.model import StripedHyena
+    from evo_amd.synthetic import synthetic_state_dict
+    cfgd = dict(vocab_size=512, hidden_size=4096, num_layers=4, attn_layer_idxs=[1], num_attention_heads=32)
+    m = StripedHyena(dict(cfgd))
+    sd = synthetic_state_dict(m, seed=5, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to_bfloat16_except_poles_residues()
+    m = m.to(DEV)
+    o = R.RefStripedHyena(R.RefConfig.from_dict(cfgd), sd, "fp32", device=DEV)
+    ob = R.RefStripedHyena(R.RefConfig.from_dict(cfgd), sd, "bf16", device=DEV)
+    assert m.ops.hyena_tail_split
+    with torch.inference_mode():
+        for B, L in ((4, 1024), (1, 512)):
+            ids = acgt_ids(B, L, seed=300)
+            got = {}
+            for split in (True, False):
+                m.ops.hyena_tail_split = split
+                m.ops.timer = KernelTimer()
+                try:
+                    got[split] = m(ids.to(DEV))[0].float()
+                    torch.cuda.synchronize()
+                    ks = {k: v[0] for k, v in m.ops.timer.summary().items()}
+                finally:
+                    m.ops.timer = None
+                    m.ops.hyena_tail_split = True
+                assert ks.get("hyena_mfma", 0) == 3 and ks.get("gemv_hyena", 0) == (3 if split else 0), (split, ks)
+            ref, flo = o(ids)[0].float(), ob(ids)[0].float()
+            # Hyena block 0 sees identical main rows; behind the attention block every row depends on all earlier ones only (causal), and the
+            # last row is nobody's "earlier": the main rows are the same bits in both routings
+            assert torch.equal(got[True][:, :L], got[False][:, :L])
+            e = {s_: rel_l2_rows(g[:, L:], ref[:, L:]).max().item() for s_, g in got.items()}
+            f = rel_l2_rows(flo[:, L:], ref[:, L:]).max().item()
+            d = rel_l2_rows(got[True][:, L:], got[False][:, L:]).max().item()
+            print(f"[tail token] {B} x {L + 1}: last row's logits vs fp32 oracle -- single-token launch {e[True]:.3e}, ragged tile {e[False]:.3e}, eager-bf16 "
+                  f"{f:.3e}; between the two routings {d:.3e}")
+            assert e[True] <= max(1.25 * e[False], 0.9 * f) and e[True] <= 1.1 * f, (e, f)
