@@ -408,7 +408,20 @@ __global__ __launch_bounds__(HT_THREADS, 1) void hyena_ct_kernel(HtArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 carry[cc][r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[r]), 0x121, 0xf, 0xf, false));
-            if (WS && last_tile) {
+            if (WS && last_tile && Ti - t0 == HT_TT) {
+                // a FULL last tile (T a multiple of 512: the scoring path's main tokens, an 8,192-token prompt): the state after its last
+                // step IS the carry the next tile would enter with -- already in the la = 0 lanes, components 4 lq .. 4 lq + 3, the layout
+                // of s0 / s_out.  (The general path below walks the last block's 32 steps serially: ~1.6 us per row and channel pair,
+                // half a tile's time -- measured as 20 us of a 440 us launch at 8 x 8,192.)
+                if (la == 0) {                               // (four dword stores from the carry registers themselves: a 16-byte store wants a copy in
+                    //                                              four consecutive registers, and this instantiation has none to spare)
+                    const float* so = a.s_out + ((int64_t)c.b * a.D + d0 + ch0 + cc) * 16;      // wave-uniform
+                    const uint32_t vo = (uint32_t)lq * 16u;
+                    asm volatile("global_store_dword %0, %1, %5\n\tglobal_store_dword %0, %2, %5 offset:4\n\t"
+                                 "global_store_dword %0, %3, %5 offset:8\n\tglobal_store_dword %0, %4, %5 offset:12\n\ts_nop 1"
+                                 :: "v"(vo), "v"(carry[cc][0]), "v"(carry[cc][1]), "v"(carry[cc][2]), "v"(carry[cc][3]), "s"(so) : "memory");
+                }
+            } else if (WS && last_tile) {
                 // state after the last token T - 1, which sits in block a_ at local step r_ - 1: the recurrence over the block's first
                 // r_ steps from the state entering it.  Lane s (< 8) takes mode s.  The x values are the very bf16 terms the matrix
                 // cores consumed: the channel's fragments go through the wave's scratch planes (hi | lo, time-contiguous).

@@ -130,7 +130,8 @@ int evo_hyena_apply(const void* z, const void* z_halo, const void* fir_w, const 
  *   table  [D, 52, 64] u32: per-channel MFMA operand constants (evo_amd/hyena_tables.py mfma_operand_table; filter.D folded into
  *          the block-Toeplitz diagonal)
  *   s0     [B, D, 8] c64 or NULL: modal state entering t = 0 (resumed prefill / sequence-parallel carry-in)
- *   s_out  [B, D, 8] c64 or NULL: state after t = T-1; needs `poles` [D, 8] c64 (fp32 pairs)
+ *   s_out  [B, D, 8] c64 or NULL: state after t = T-1; needs `poles` [D, 8] c64 (fp32 pairs).  T % 512 == 0: the carry of the last tile, stored
+ *          from registers; otherwise the last block's steps are walked from the state entering it (fp32 recurrence, ~half a tile's time per row)
  *   state_only != 0: no y (may be NULL), only s_out -- stage 1 of a sequence-parallel shard, whose end state from a zero carry-in
  *          goes to the other ranks before anybody can finish its outputs (new; the reference has no multi-GPU path)
  *   y      [B, T, D] bf16, or with y_blocked_rows != 0 BLOCKED: [ceil(y_blocked_rows / 128)][D / 16][128][16] bf16 -- the
