@@ -9,7 +9,7 @@ import sys
 
 rows = {}
 for line in open(sys.argv[1]):
-    if "hyena_ct_kernel<false, false>" not in line:
+    if "hyena_ct_kernel<false, " not in line:        # <false, true>: the scoring path's launch since round 6 (main tokens, end state out); <false, false>: the ragged-tile form
         continue
     f = line.split()
     name = [x for x in f if x.startswith("TCC_")][0]

@@ -18,7 +18,11 @@ dskip = rn(D, std=0.5).bfloat16(); tab = mfma_operand_table(poles, res, dskip)
 for (B, T) in (((8, 8193), (1, 131073)) if os.environ.get("HC_SHAPES") is None else eval(os.environ["HC_SHAPES"])):
     Tm, Tp, Mp, r_tail = ops.zt_layout(B, T)
     zt = rn(Mp // 256 + (1 if r_tail else 0), 3 * D, 256).bfloat16()
+    split = r_tail == 1 and getattr(ops, "hyena_tail_split", False) and os.environ.get("HC_TAIL_IN_OPERATOR") is None
     for _ in range(3):
-        ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
+        if split:       # the scoring path's launch since round 6: the 512 k main tokens of every row, end state out (the last token: the fused single-token launch)
+            ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, want_state=True, poles=poles, y_blk=ops.yblk_empty(B * T, D, dev), main_only=True)
+        else:
+            ops.hyena_ct(zt, B, T, fir_w, fir_b, tab, H, y_blk=ops.yblk_empty(B * T, D, dev))
     torch.cuda.synchronize()
 print("done")
