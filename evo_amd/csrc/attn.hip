@@ -655,6 +655,78 @@ __global__ __launch_bounds__(256) void attn_decode_stream_kernel(AttnArgs a) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#ifndef ATTN_DECODE_PIPE
+#define ATTN_DECODE_PIPE 1                   // 1 (round 6): 32-key half blocks, the next half's 16 requests in flight while this one is reduced; 0: whole 64-key blocks, load then compute
+#endif
+#if ATTN_DECODE_PIPE
+    // A wave's blocks in HALVES of 32 keys (8 steps), double-buffered: the requests of half j + 1 go out before half j is reduced, so a
+    // wave keeps 16-32 KiB in flight all the time.  (Whole blocks, loaded then reduced: at 8 k keys and 64 splits a wave has two blocks,
+    // i.e. two exposed round trips with the CU's request queue draining while all its waves reduce -- 41 us for 134 MB, 3.3 TB/s.)
+    const int nhalf = (int)((n_keys + 31) >> 5);
+    const int nb_my = split < nblk ? (nblk - split + a.n_splits - 1) / a.n_splits : 0;
+    auto half_of = [&](int jh) { return 2 * (split + (jh >> 1) * a.n_splits) + (jh & 1); };
+    int n_my = 2 * nb_my;
+    if (n_my > 0 && half_of(n_my - 1) >= nhalf) --n_my;     // the last block's second half may lie beyond the keys
+    auto load_half = [&](int jh, uint4 (&kr)[8], uint4 (&vr)[8]) {
+        const int64_t k0 = (int64_t)half_of(jh) * 32 + ks;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int64_t key = k0 + 4 * i;
+            key = key < n_keys ? key : n_keys - 1;           // a ragged last half re-reads the last key (masked below)
+            kr[i] = ld16(kp, (uint32_t)key * kst + dco);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int64_t key = k0 + 4 * i;
+            key = key < n_keys ? key : n_keys - 1;
+            vr[i] = ld16(vp, (uint32_t)key * vst + dco);
+        }
+    };
+    auto reduce_half = [&](int jh, const uint4 (&kr)[8], const uint4 (&vr)[8]) {
+        const int64_t k0 = (int64_t)half_of(jh) * 32 + ks;
+        float sc[8];
+        float mb = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float d = attn_dot8(kr[i], qv);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            d += __shfl_xor(d, 8, 64);
+            sc[i] = k0 + 4 * i < n_keys ? d * a.scale_log2 : -INFINITY;
+            mb = fmaxf(mb, sc[i]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_run, mb);                // finite: the half holds at least one key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float pw = __builtin_amdgcn_exp2f(sc[i] - m_new);
+            l_run += pw;
+            o[0] = fmaf(pw, bf_lo(vr[i].x), o[0]); o[1] = fmaf(pw, bf_hi(vr[i].x), o[1]);
+            o[2] = fmaf(pw, bf_lo(vr[i].y), o[2]); o[3] = fmaf(pw, bf_hi(vr[i].y), o[3]);
+            o[4] = fmaf(pw, bf_lo(vr[i].z), o[4]); o[5] = fmaf(pw, bf_hi(vr[i].z), o[5]);
+            o[6] = fmaf(pw, bf_lo(vr[i].w), o[6]); o[7] = fmaf(pw, bf_hi(vr[i].w), o[7]);
+        }
+        m_run = m_new;
+    };
+    {
+        uint4 kA[8], vA[8], kB[8], vB[8];
+        if (n_my > 0) load_half(0, kA, vA);
+        for (int jh = 0; jh < n_my; jh += 2) {               // two halves per trip: the buffers alternate without register copies
+            if (jh + 1 < n_my) load_half(jh + 1, kB, vB);
+            reduce_half(jh, kA, vA);
+            if (jh + 1 < n_my) {
+                if (jh + 2 < n_my) load_half(jh + 2, kA, vA);
+                reduce_half(jh + 1, kB, vB);
+            }
+        }
+    }
+#else
     for (int blk = split; blk < nblk; blk += a.n_splits) {
         const int64_t k0 = (int64_t)blk * 64 + ks;
         uint4 kr[16], vr[16];
@@ -700,6 +772,7 @@ __global__ __launch_bounds__(256) void attn_decode_stream_kernel(AttnArgs a) {
         }
         m_run = m_new;
     }
+#endif
     // the four key groups of the wave meet (every lane of a group carries the same l)
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);

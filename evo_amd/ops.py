@@ -886,9 +886,11 @@ class HipOps:
                 raise RuntimeError(f"attention_decode {nm}: need a ROCm bf16 tensor with a dense last dim")
         Tk = k.shape[1]
         if n_splits is None:                     # one split per WAVE of the streaming kernel, whole workgroups of four, at most
-            # one per 64-key block.  Measured on MI355X (tools/experiments/attn_decode_bench.py): 64 is best from 8 k to 131 k keys
-            # at batch 1-3 (a wave is latency-bound on its own blocks: more, shorter waves win until the partials cost more)
-            n_splits = min(((Tk + 63) // 64 + 3) // 4 * 4, 64 if B * H <= 128 else 32)
+            # one per 64-key block.  Measured on MI355X (tools/experiments/attn_decode_bench.py, round 6: the kernel keeps the next 32-key
+            # half's requests in flight while it reduces the current one): 32 is best from 8 k to 131 k keys at batch 1-3 (29.5 / 78.7 /
+            # 102 / 384 us at 1 x 8 k / 3 x 8 k / 32 k / 131 k; 64 splits: 31.7 / 81.3 / 107 / 385; the load-then-reduce loop of rounds
+            # 3-5 wanted 64 and took 36.8 / 94.5 / 118 / 428)
+            n_splits = min(((Tk + 63) // 64 + 3) // 4 * 4, 32)
         o = torch.empty(B, 1, H, hd, dtype=torch.bfloat16, device=q.device)
         part_o = torch.empty(B, H, n_splits, hd, dtype=torch.float32, device=q.device)
         part_ml = torch.empty(B, H, n_splits, 2, dtype=torch.float32, device=q.device)

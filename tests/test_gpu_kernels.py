@@ -479,7 +479,10 @@ def test_attention_4k_causal(ops, pre):
 
 
 # ------------------------------------------------------------------------------------------------ decode attention
-@pytest.mark.parametrize("B,H,Tk,splits", [(1, 2, 1, None), (2, 2, 300, None), (1, 4, 8193, 8), (3, 2, 700, 1), (1, 2, 130, 5)])
+@pytest.mark.parametrize("B,H,Tk,splits", [(1, 2, 1, None), (2, 2, 300, None), (1, 4, 8193, 8), (3, 2, 700, 1), (1, 2, 130, 5),
+                                            # round 6 (32-key halves, double-buffered): a last block with one key / exactly one half / one key into
+                                            # its second half, more splits than blocks, long runs of halves per wave
+                                            (1, 2, 65, 3), (1, 2, 96, 2), (2, 3, 2048 + 33, None), (1, 2, 32, 4), (1, 1, 20000, 4)])
 def test_attention_decode_matches_oracle(ops, B, H, Tk, splits):
     q = bf(torch.randn(B, 1, H, 128, generator=gen(30)))
     kv = bf(torch.randn(B, Tk + 37, 2, H, 128, generator=gen(31)))           # cache with slack past Tk
