@@ -637,34 +637,45 @@ typedef float gv_f32x4 __attribute__((ext_vector_type(4)));
 // MT (round 6): m tiles of 16 batch rows per weight pass -- 17 <= M <= 64 rows (the pooled decode step at 17-64 live slots; small prefill
 // batches) stream the weights ONCE with MT MFMAs per weight fragment.  Until round 5 those batches ran the persistent 256 x 256 GEMM:
 // N / 256 of the 256 CUs busy, 0.5-1.3 TB/s of weights (profiles/r06_pool32_kernel_stats.txt: 80 % of a 32-slot pooled step).
-template <int MT>
+// NT (round 6): n tiles of 16 weight rows per workgroup sharing every x fragment -- at 17-64 batch rows a weight fragment (1 KiB per wave) pulled
+// MT x fragments of the same size through L2 / L1 (2.1 TB/s of weights at 32 rows, 1.5 at 64: tools/bench_gemv.py); two n tiles halve that.
+template <int MT, int NT>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                           const uint16_t* __restrict__ bias, const uint16_t* res,
                                                           uint16_t* y, int M, int N, int nvec) {   // res may alias y
-    __shared__ gv_f32x4 part[MT][8][64];
+    static_assert(MT * NT <= 8, "one reducing wave per (n tile, m tile)");
+    __shared__ gv_f32x4 part[NT * MT][8][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kb = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
+    const int n0 = blockIdx.x * 16 * NT;
     const int nsteps = nvec >> 2;                                // 32 k per MFMA = 4 vectors of 8
     const int s0 = (int)((int64_t)nsteps * wave / 8), s1 = (int)((int64_t)nsteps * (wave + 1) / 8);
-    const uint4* wp = w + (int64_t)nrow * nvec + kb;
+    const uint4* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nrow = n0 + 16 * j + r16 < N ? n0 + 16 * j + r16 : N - 1;
+        wp[j] = w + (int64_t)nrow * nvec + kb;
+    }
     const uint4* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int mrow = 16 * t + r16 < M ? 16 * t + r16 : M - 1;
         xp[t] = x + (int64_t)mrow * nvec + kb;
     }
-    gv_f32x4 acc[MT];
+    gv_f32x4 acc[NT][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = gv_f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = MT == 1 ? 8 : (MT == 2 ? 4 : 2);           // weight fragments in flight per trip (x fragments: U * MT)
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[j][t] = gv_f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = NT * MT == 1 ? 8 : (NT + MT <= 4 ? 4 : 2);     // steps per trip: U * (NT weight + MT x) fragments requested together
     int s = s0;
     for (; s + U <= s1; s += U) {
-        uint4 wf[U], xf[MT][U];
+        uint4 wf[NT][U], xf[MT][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = ld_stream(wp + 4 * (s + u));
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[j][u] = ld_stream(wp[j] + 4 * (s + u));
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -672,31 +683,137 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(const uint4* __restric
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[u]), __builtin_bit_cast(bf16x8_t, xf[t][u]),
-                                                                 acc[t], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j][u]), __builtin_bit_cast(bf16x8_t, xf[t][u]),
+                                                                        acc[j][t], 0, 0, 0);
     }
     for (; s < s1; ++s) {
-        const uint4 wv = ld_stream(wp + 4 * s);
+        uint4 xv[MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xp[t][4 * s]), acc[t], 0, 0, 0);
+        for (int t = 0; t < MT; ++t) xv[t] = xp[t][4 * s];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint4 wv = ld_stream(wp[j] + 4 * s);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xv[t]), acc[j][t], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) part[t][wave][lane] = acc[t];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) part[j * MT + t][wave][lane] = acc[j][t];
     __syncthreads();
-    // the eight partial tiles of m tile t meet in wave t (MT <= 4 of the 8 waves store): bias / residual added in fp32, one rounding
-    if (wave < MT) {
+    // the eight partial tiles of (n tile j, m tile t) meet in wave j MT + t: bias / residual added in fp32, one rounding
+    if (wave < NT * MT) {
         gv_f32x4 a_ = part[wave][0][lane];
 #pragma unroll
         for (int q = 1; q < 8; ++q) a_ += part[wave][q][lane];
-        const int m = 16 * wave + r16;
+        const int jt = wave / MT, tt = wave - jt * MT;
+        const int m = 16 * tt + r16;
+        if (m < M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * jt + 4 * kb + r;
+                if (n < N) {
+                    float o = a_[r] + (bias ? bf_to_f(bias[n]) : 0.f);
+                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
+                    y[(int64_t)m * N + n] = f_to_bf(o);
+                }
+            }
+        }
+    }
+}
+
+// ---- 5 <= M <= 64, N >= 8192: n-split form (round 6).  The k-split form above is bound by L2, not by HBM: every weight fragment (1 KiB per
+// wave) pulls MT x fragments of the same size through L2 -- weights + x add up to 6-7 TB/s at every M (4.0 TB/s of weights at 8 rows, 3.4 at
+// 16, 2.2 at 32, 1.5 at 64; tools/bench_gemv.py) where hipBLASLt streams 4.2 TB/s at 32-64 rows.  Here a workgroup is WAVES waves, each owning a
+// 16-row n tile for the WHOLE K (no partial sums, no reduction), and the x rows of a 256-k chunk are staged in LDS once per workgroup and
+// read by all its waves as B fragments (ds_read_b128, conflict-free at a row pitch of 528 B): x costs L2 MT / WAVES of the weight bytes
+// instead of MT.  Weight fragments of chunk c + 1 and the x rows of chunk c + 1 are requested before chunk c is multiplied.  K % 256 == 0.
+template <int MT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void skinny_n_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                              const uint16_t* __restrict__ bias, const uint16_t* res,
+                                                              uint16_t* y, int M, int N, int nvec) {   // res may alias y
+    constexpr int KC = 8, ROWB = KC * 64 + 16;                   // steps per chunk; LDS bytes per x row (512 + 16 pad)
+    constexpr int XL = (MT * 16 * KC * 4 + 64 * WAVES - 1) / (64 * WAVES);   // 16-byte pieces of an x chunk per thread
+    __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kb = lane >> 4;
+    const int n0 = (blockIdx.x * WAVES + wave) * 16;
+    const int nrow = n0 + r16 < N ? n0 + r16 : N - 1;
+    const uint4* wp = w + (int64_t)nrow * nvec + kb;
+    const int n_chunk = nvec / (KC * 4);
+    gv_f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = gv_f32x4{0.f, 0.f, 0.f, 0.f};
+    // x chunk pieces of this thread: piece p = tid + i * threads -> row p / 32 (32 pieces of 16 B per 512-byte row), column p % 32
+    // (native vectors, not HIP's uint4 struct: as a loop-carried, conditionally written array of uint4 the pieces stayed in scratch memory)
+    typedef unsigned int sn_u32x4 __attribute__((ext_vector_type(4)));
+    sn_u32x4 xr[XL];
+#define SN_X_LOAD(C)                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < XL; ++i_) {                                                       \
+        const int pidx_ = tid + i_ * 64 * WAVES;                                                              \
+        int row_ = pidx_ >> 5;                                                                                \
+        row_ = row_ < M ? row_ : M - 1;              /* rows past M (and pieces past the chunk) re-read a valid row: never stored */ \
+        xr[i_] = *(const sn_u32x4*)(x + (int64_t)row_ * nvec + (C) * (KC * 4) + (pidx_ & 31));               \
+    }
+#define SN_X_STORE(BUF)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < XL; ++i_) {                                                       \
+        const int pidx_ = tid + i_ * 64 * WAVES;                                                              \
+        if (pidx_ < MT * 16 * 32) *(sn_u32x4*)(xs[BUF] + (pidx_ >> 5) * ROWB + (pidx_ & 31) * 16) = xr[i_];   \
+    }
+#ifndef SN_PROBE_CONTIG
+#define SN_PROBE_CONTIG 0                    // measurement only (WRONG results): weight fragments read as if stored fragment-major, 1 KiB contiguous per request
+#endif
+    auto w_load = [&](int c, uint4 (&wf)[KC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+            wf[u] = SN_PROBE_CONTIG ? ld_stream(w + ((int64_t)(n0 >> 4) * (nvec >> 2) + c * KC + u) * 64 + lane) : ld_stream(wp + 4 * (c * KC + u));
+    };
+    auto mul = [&](int buf, const uint4 (&wf)[KC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const uint4 xv = *(const uint4*)(xs[buf] + (16 * t + r16) * ROWB + u * 64 + kb * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[u]), __builtin_bit_cast(bf16x8_t, xv), acc[t], 0, 0, 0);
+            }
+    };
+    // weight fragments: chunk c multiplies while c + 1 is in flight (a ring of three -- 16 KiB per wave in flight -- measured 5-8 % SLOWER: the form is
+    // not latency-bound; what caps it is the access pattern, 64-byte pieces of 16 rows per request: read as if the weight were stored fragment-major
+    // (1 KiB contiguous per request, SN_PROBE_CONTIG) the same kernel streams 4.3-4.4 TB/s at 17-32 rows, hipBLASLt's rate, instead of 3.1-3.3)
+    uint4 wA[KC], wB[KC];
+    SN_X_LOAD(0);
+    w_load(0, wA);
+    SN_X_STORE(0);
+    __syncthreads();
+#define SN_STAGE(C, WCUR, WNEXT, BUF)                                                                         \
+    if ((C) < n_chunk) {                                                                                      \
+        if ((C) + 1 < n_chunk) { SN_X_LOAD((C) + 1); w_load((C) + 1, WNEXT); }                                \
+        mul(BUF, WCUR);                                                                                       \
+        if ((C) + 1 < n_chunk) { SN_X_STORE((BUF) ^ 1); }                                                     \
+        __syncthreads();                                                                                      \
+    }
+    for (int c = 0; c < n_chunk; c += 2) {                       // two chunks per trip: the fragment sets alternate without register copies
+        SN_STAGE(c, wA, wB, 0) SN_STAGE(c + 1, wB, wA, 1)
+    }
+#undef SN_STAGE
+#undef SN_X_LOAD
+#undef SN_X_STORE
+    // D[n][m]: lane holds n = n0 + 4 kb + r, m = 16 t + r16 -- four consecutive output columns of its row
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + r16;
         if (m < M) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 4 * kb + r;
                 if (n < N) {
-                    float o = a_[r] + (bias ? bf_to_f(bias[n]) : 0.f);
+                    float o = acc[t][r] + (bias ? bf_to_f(bias[n]) : 0.f);
                     if (res) o += bf_to_f(res[(int64_t)m * N + n]);
                     y[(int64_t)m * N + n] = f_to_bf(o);
                 }
@@ -857,11 +974,29 @@ extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void*
     if (M > 8 && K % 32 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (M >= 5 && K % 32 == 0) {
-        const dim3 grid((unsigned)((N + 15) / 16)), block(512);
-#define EVO_SK(MT)                                                                                                         \
-        hipLaunchKernelGGL(skinny_mfma_kernel<MT>, grid, block, 0, s, (const uint4*)x, (const uint4*)w, (const uint16_t*)bias,  \
-                           (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)(K / 8))
-        if (M <= 16) EVO_SK(1); else if (M <= 32) EVO_SK(2); else if (M <= 48) EVO_SK(3); else EVO_SK(4);
+        // two n tiles per workgroup (every x fragment feeds two weight fragments) where that still leaves a workgroup or more per CU
+        static const int nt_env = [] { const char* e = getenv("EVO_SK_NT"); return e ? atoi(e) : 0; }();      // measurement knob: 1 / 2 force, 0 = auto
+        const int nt = nt_env ? nt_env : (N >= 8192 && M > 16 ? 2 : 1);
+        const dim3 block(512);
+        // n-split form: wide layers (a workgroup or more per CU with WAVES n tiles per workgroup), K in whole 256-k chunks
+        static const int ns_env = [] { const char* e = getenv("EVO_SK_NSPLIT"); return e ? atoi(e) : -1; }();  // measurement knob: 0 off, 2 / 4 force WAVES
+        // (measured, tools/bench_gemv.py: ahead of the k-split form from 17 rows up on the wide layers -- 2.2 -> 3.3+ TB/s at 32 rows, 1.4 -> 2.9 at 64;
+        //  behind it at <= 16 rows, where x is a small share of the L2 traffic and the k-split form's 11,000 short waves hide latency better)
+        const int waves_n = ns_env >= 0 ? ns_env : (K % 256 == 0 && N >= 8192 && M > 16 ? 4 : 0);
+        if (waves_n && K % 256 == 0) {
+#define EVO_SN(MT, WV)                                                                                                     \
+            hipLaunchKernelGGL((skinny_n_kernel<MT, WV>), dim3((unsigned)((N + 16 * WV - 1) / (16 * WV))), dim3(64 * WV), 0, s, (const uint4*)x,  \
+                               (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)(K / 8))
+            if (waves_n == 4) { if (M <= 16) EVO_SN(1, 4); else if (M <= 32) EVO_SN(2, 4); else if (M <= 48) EVO_SN(3, 4); else EVO_SN(4, 4); }
+            else { if (M <= 16) EVO_SN(1, 2); else if (M <= 32) EVO_SN(2, 2); else if (M <= 48) EVO_SN(3, 2); else EVO_SN(4, 2); }
+#undef EVO_SN
+            return evo_launch_status();
+        }
+#define EVO_SK(MT, NT)                                                                                                     \
+        hipLaunchKernelGGL((skinny_mfma_kernel<MT, NT>), dim3((unsigned)((N + 16 * NT - 1) / (16 * NT))), block, 0, s, (const uint4*)x, (const uint4*)w, \
+                           (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)(K / 8))
+        if (nt == 2) { if (M <= 16) EVO_SK(1, 2); else if (M <= 32) EVO_SK(2, 2); else if (M <= 48) EVO_SK(3, 2); else EVO_SK(4, 2); }
+        else { if (M <= 16) EVO_SK(1, 1); else if (M <= 32) EVO_SK(2, 1); else if (M <= 48) EVO_SK(3, 1); else EVO_SK(4, 1); }
 #undef EVO_SK
         return evo_launch_status();
     }

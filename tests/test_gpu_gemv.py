@@ -8,7 +8,10 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 11, 16, 17, 32, 33, 48, 49, 64])
-@pytest.mark.parametrize("N,K", [(12288, 4096), (4096, 10928), (4096, 11008), (512, 4096), (37, 264), (37, 288)])
+@pytest.mark.parametrize("N,K", [(12288, 4096), (4096, 10928), (4096, 11008), (512, 4096), (37, 264), (37, 288),
+                                 # round 6, the n-split MFMA form (N >= 8192, K % 256 == 0; x rows of a 256-k chunk staged in LDS once per workgroup): four
+                                 # waves per workgroup (N >= 16,384), a ragged last n tile with idle waves, one / three chunks of K
+                                 (22016, 4096), (8200, 768), (8200, 256)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual"])
 def test_linear_small_m(M, N, K, mode):
     from evo_amd.ops import default_ops

@@ -27,7 +27,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-for M in (1, 2, 4, 5, 8, 12, 16):
+for M in [int(x) for x in os.environ.get("GEMV_MS", "1,2,4,5,8,12,16,32,48,64").split(",")]:
     tot_mine = tot_torch = 0.0
     line = []
     for name, N, K in (("proj", 12288, 4096), ("out", 4096, 4096), ("l1l2", 22016, 4096), ("l3", 4096, 11008)):
