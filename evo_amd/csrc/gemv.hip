@@ -822,6 +822,106 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_n_kernel(const uint4* __res
     }
 }
 
+// ---- the n-split form with CONTIGUOUS weight requests (round 6, second step).  skinny_n_kernel asks for a weight fragment as the MFMA wants it: 64 bytes
+// of each of 16 rows that lie K * 2 bytes apart -- and streams 3.1-3.3 TB/s where the same kernel reading 1 KiB contiguous per request runs 4.3-4.4
+// (profiles/r06_small_m_nsplit_ab.txt).  Here a request covers RPI = 2 (4) whole row pieces of 512 (256) contiguous bytes, the wave parks the chunk in a
+// PRIVATE LDS region in row order and reads its fragments back from there (ds_write_b128 / ds_read_b128, both conflict-free at the padded row pitch);
+// the requests of chunk c + 1 are in flight while chunk c multiplies.  Everything else as skinny_n_kernel.
+template <int MT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                               const uint16_t* __restrict__ bias, const uint16_t* res,
+                                                               uint16_t* y, int M, int N, int nvec) {   // res may alias y
+    constexpr int KC = MT <= 2 ? 8 : 4;                          // MFMA steps (32 k) per chunk
+    constexpr int ROWB = KC * 64 + 16;                           // LDS bytes per row of a chunk (+ 16 pad: b128 accesses at this pitch touch all banks)
+    constexpr int PPR = KC * 4;                                  // 16-byte pieces per row of a chunk
+    constexpr int RPI = 64 / PPR;                                // weight rows per request
+    constexpr int XL = (MT * 16 * PPR + 64 * WAVES - 1) / (64 * WAVES);   // x pieces per thread and chunk
+    __shared__ __attribute__((aligned(16))) unsigned char xs[2][MT * 16 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char wsm[WAVES][16 * ROWB];
+    typedef unsigned int sn_u32x4 __attribute__((ext_vector_type(4)));   // (native vectors: loop-carried uint4 arrays end up in scratch memory)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kb = lane >> 4;
+    const int n0 = (blockIdx.x * WAVES + wave) * 16;
+    const int n_chunk = nvec / PPR;
+    // request i of a chunk: weight row n0 + RPI i + lane / PPR, piece lane % PPR
+    const int q_row = lane / PPR, q_piece = lane % PPR;
+    const sn_u32x4* wq[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const int row = n0 + RPI * i + q_row < N ? n0 + RPI * i + q_row : N - 1;
+        wq[i] = (const sn_u32x4*)(w + (int64_t)row * nvec + q_piece);
+    }
+    unsigned char* wmine = wsm[wave];
+    const int w_st = q_row * ROWB + q_piece * 16;               // + RPI * i * ROWB
+    const int f_rd = r16 * ROWB + kb * 16;                       // + u * 64
+    gv_f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = gv_f32x4{0.f, 0.f, 0.f, 0.f};
+    sn_u32x4 xr[XL], wr[KC];
+#define SW_X_LOAD(C)                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < XL; ++i_) {                                                       \
+        const int pidx_ = tid + i_ * 64 * WAVES;                                                              \
+        int row_ = pidx_ / PPR;                                                                               \
+        row_ = row_ < M ? row_ : M - 1;              /* rows past M (and pieces past the chunk) re-read a valid row: never stored */ \
+        xr[i_] = *(const sn_u32x4*)(x + (int64_t)row_ * nvec + (C) * PPR + (pidx_ % PPR));                    \
+    }
+#define SW_X_STORE(BUF)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < XL; ++i_) {                                                       \
+        const int pidx_ = tid + i_ * 64 * WAVES;                                                              \
+        if (pidx_ < MT * 16 * PPR) *(sn_u32x4*)(xs[BUF] + (pidx_ / PPR) * ROWB + (pidx_ % PPR) * 16) = xr[i_]; \
+    }
+#define SW_W_LOAD(C) _Pragma("unroll") for (int i_ = 0; i_ < KC; ++i_) wr[i_] = __builtin_nontemporal_load(wq[i_] + (C) * PPR);
+#define SW_W_STORE() _Pragma("unroll") for (int i_ = 0; i_ < KC; ++i_) *(sn_u32x4*)(wmine + w_st + RPI * i_ * ROWB) = wr[i_];
+    auto mul = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            const uint4 wv = *(const uint4*)(wmine + f_rd + u * 64);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const uint4 xv = *(const uint4*)(xs[buf] + (16 * t + r16) * ROWB + u * 64 + kb * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xv), acc[t], 0, 0, 0);
+            }
+        }
+    };
+    SW_X_LOAD(0);
+    SW_W_LOAD(0);
+    SW_X_STORE(0);
+    SW_W_STORE();
+    __syncthreads();
+    for (int c = 0; c < n_chunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunk) { SW_X_LOAD(c + 1); SW_W_LOAD(c + 1); }
+        mul(buf);
+        // no barrier here: x buffer buf ^ 1 has been free since the last barrier, and the weight region is the wave's own -- its stores follow its reads
+        // in program order (same LDS array: the compiler keeps the order, the LDS unit executes a wave's accesses in order)
+#ifdef SW_TWO_BARRIERS
+        __syncthreads();
+#endif
+        if (c + 1 < n_chunk) { SW_X_STORE(buf ^ 1); SW_W_STORE(); }
+        __syncthreads();
+    }
+#undef SW_X_LOAD
+#undef SW_X_STORE
+#undef SW_W_LOAD
+#undef SW_W_STORE
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + r16;
+        if (m < M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * kb + r;
+                if (n < N) {
+                    float o = acc[t][r] + (bias ? bf_to_f(bias[n]) : 0.f);
+                    if (res) o += bf_to_f(res[(int64_t)m * N + n]);
+                    y[(int64_t)m * N + n] = f_to_bf(o);
+                }
+            }
+        }
+    }
+}
+
 template <int M>
 static void gemv_launch(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t N, int64_t K,
                         hipStream_t s) {
@@ -983,6 +1083,19 @@ extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void*
         // (measured, tools/bench_gemv.py: ahead of the k-split form from 17 rows up on the wide layers -- 2.2 -> 3.3+ TB/s at 32 rows, 1.4 -> 2.9 at 64;
         //  behind it at <= 16 rows, where x is a small share of the L2 traffic and the k-split form's 11,000 short waves hide latency better)
         const int waves_n = ns_env >= 0 ? ns_env : (K % 256 == 0 && N >= 8192 && M > 16 ? 4 : 0);
+        static const int nw_env = [] { const char* e = getenv("EVO_SK_WLDS"); return e ? atoi(e) : 1; }();    // measurement knob: 0 = fragment-shaped weight requests (skinny_n_kernel)
+        static const int nwm_env = [] { const char* e = getenv("EVO_SK_WLDS_MINM"); return e ? atoi(e) : 5; }();    // measurement knob: first row count on the contiguous form (measured ahead of the k-split form from 5 rows up on the wide layers)
+        static const int nww_env = [] { const char* e = getenv("EVO_SK_WLDS_WAVES"); return e ? atoi(e) : 0; }();   // measurement knob: 2 / 4 waves per workgroup (0 = auto)
+        if (K % 256 == 0 && N >= 8192 && nw_env && M >= nwm_env && ns_env < 0) {
+            const int wv = nww_env ? nww_env : (N >= 256 * 64 ? 4 : (N >= 256 * 48 ? 3 : (N >= 256 * 32 ? 2 : 4)));   // a workgroup or more per CU where N allows
+#define EVO_SNW(MT, WV) hipLaunchKernelGGL((skinny_nw_kernel<MT, WV>), dim3((unsigned)((N + 16 * WV - 1) / (16 * WV))), dim3(64 * WV), 0, s, (const uint4*)x, \
+                                           (const uint4*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)(K / 8))
+            if (wv == 4) { if (M <= 16) EVO_SNW(1, 4); else if (M <= 32) EVO_SNW(2, 4); else if (M <= 48) EVO_SNW(3, 4); else EVO_SNW(4, 4); }
+            else if (wv == 3) { if (M <= 16) EVO_SNW(1, 3); else if (M <= 32) EVO_SNW(2, 3); else if (M <= 48) EVO_SNW(3, 3); else EVO_SNW(4, 3); }
+            else { if (M <= 16) EVO_SNW(1, 2); else if (M <= 32) EVO_SNW(2, 2); else if (M <= 48) EVO_SNW(3, 2); else EVO_SNW(4, 2); }
+#undef EVO_SNW
+            return evo_launch_status();
+        }
         if (waves_n && K % 256 == 0) {
 #define EVO_SN(MT, WV)                                                                                                     \
             hipLaunchKernelGGL((skinny_n_kernel<MT, WV>), dim3((unsigned)((N + 16 * WV - 1) / (16 * WV))), dim3(64 * WV), 0, s, (const uint4*)x,  \
