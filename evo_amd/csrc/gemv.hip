@@ -827,10 +827,13 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_n_kernel(const uint4* __res
 // (profiles/r06_small_m_nsplit_ab.txt).  Here a request covers RPI = 2 (4) whole row pieces of 512 (256) contiguous bytes, the wave parks the chunk in a
 // PRIVATE LDS region in row order and reads its fragments back from there (ds_write_b128 / ds_read_b128, both conflict-free at the padded row pitch);
 // the requests of chunk c + 1 are in flight while chunk c multiplies.  Everything else as skinny_n_kernel.
-template <int MT, int WAVES>
+// SPLITK (N < 8192, the two N = 4,096 layers of a block): blockIdx.y is a slice of the 256-k chunks; the slice's fp32 partial sums go to
+// ws [slices][M][N] and skinny_reduce_kernel adds them in slice order (+ bias, + residual, one rounding) -- 64 n groups x 4 slices = a workgroup
+// per CU with x still shared four ways, where the k-split form is L2-bound on x (2.1 TB/s at 32 rows).
+template <int MT, int WAVES, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                                const uint16_t* __restrict__ bias, const uint16_t* res,
-                                                               uint16_t* y, int M, int N, int nvec) {   // res may alias y
+                                                               uint16_t* y, int M, int N, int nvec, float* __restrict__ ws = nullptr) {   // res may alias y
     constexpr int KC = MT <= 2 ? 8 : 4;                          // MFMA steps (32 k) per chunk
     constexpr int ROWB = KC * 64 + 16;                           // LDS bytes per row of a chunk (+ 16 pad: b128 accesses at this pitch touch all banks)
     constexpr int PPR = KC * 4;                                  // 16-byte pieces per row of a chunk
@@ -843,7 +846,9 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kb = lane >> 4;
     const int n0 = (blockIdx.x * WAVES + wave) * 16;
-    const int n_chunk = nvec / PPR;
+    const int n_chunk_all = nvec / PPR;
+    const int c_first = SPLITK ? (int)((int64_t)n_chunk_all * blockIdx.y / gridDim.y) : 0;
+    const int n_chunk = SPLITK ? (int)((int64_t)n_chunk_all * (blockIdx.y + 1) / gridDim.y) : n_chunk_all;   // chunks [c_first, n_chunk) are this workgroup's
     // request i of a chunk: weight row n0 + RPI i + lane / PPR, piece lane % PPR
     const int q_row = lane / PPR, q_piece = lane % PPR;
     const sn_u32x4* wq[KC];
@@ -884,12 +889,12 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
             }
         }
     };
-    SW_X_LOAD(0);
-    SW_W_LOAD(0);
-    SW_X_STORE(0);
+    SW_X_LOAD(c_first);
+    SW_W_LOAD(c_first);
+    SW_X_STORE(c_first & 1);
     SW_W_STORE();
     __syncthreads();
-    for (int c = 0; c < n_chunk; ++c) {
+    for (int c = c_first; c < n_chunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunk) { SW_X_LOAD(c + 1); SW_W_LOAD(c + 1); }
         mul(buf);
@@ -905,6 +910,15 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
 #undef SW_X_STORE
 #undef SW_W_LOAD
 #undef SW_W_STORE
+    if constexpr (SPLITK) {
+        float* wsl = ws + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = 16 * t + r16;
+            if (m < M && n0 + 4 * kb < N) *(gv_f32x4*)(wsl + (int64_t)m * N + n0 + 4 * kb) = acc[t];     // (N % 4 == 0 on this path)
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = 16 * t + r16;
@@ -920,6 +934,24 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
             }
         }
     }
+}
+
+// y [M, N] = sum over slices of ws [slices][M][N] (in slice order: deterministic) + bias + residual, one rounding; a thread owns four columns
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ ws, const uint16_t* __restrict__ bias, const uint16_t* res,
+                                                            uint16_t* y, int M, int N, int slices) {   // res may alias y
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)M * N / 4;
+    if (q >= total) return;
+    const int64_t e = q * 4;
+    const int n = (int)(e % N);
+    gv_f32x4 a = *(const gv_f32x4*)(ws + e);
+    for (int sl = 1; sl < slices; ++sl) a += *(const gv_f32x4*)(ws + (int64_t)sl * M * N + e);
+    float o[4] = {a[0], a[1], a[2], a[3]};
+    if (bias) { const uint2 b = *(const uint2*)(bias + n); o[0] += bf_lo(b.x); o[1] += bf_hi(b.x); o[2] += bf_lo(b.y); o[3] += bf_hi(b.y); }
+    if (res) { const uint2 r = *(const uint2*)(res + e); o[0] += bf_lo(r.x); o[1] += bf_hi(r.x); o[2] += bf_lo(r.y); o[3] += bf_hi(r.y); }
+    uint2 out;
+    out.x = pack_bf2(o[0], o[1]);
+    out.y = pack_bf2(o[2], o[3]);
+    *(uint2*)(y + e) = out;
 }
 
 template <int M>
@@ -1069,7 +1101,7 @@ extern "C" int evo_norm_mlp_gate_small_m_bf16(const void* x, const void* scale, 
 }
 
 extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
-                                       int64_t M, int64_t N, int64_t K, void* stream) {
+                                       int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, void* stream) {
     if (M < 1 || M > 64 || N <= 0 || K <= 0 || K % 8 != 0 || N > 0x7fffffff - 16) return -1;
     if (M > 8 && K % 32 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -1086,6 +1118,26 @@ extern "C" int evo_linear_small_m_bf16(const void* x, const void* w, const void*
         static const int nw_env = [] { const char* e = getenv("EVO_SK_WLDS"); return e ? atoi(e) : 1; }();    // measurement knob: 0 = fragment-shaped weight requests (skinny_n_kernel)
         static const int nwm_env = [] { const char* e = getenv("EVO_SK_WLDS_MINM"); return e ? atoi(e) : 5; }();    // measurement knob: first row count on the contiguous form (measured ahead of the k-split form from 5 rows up on the wide layers)
         static const int nww_env = [] { const char* e = getenv("EVO_SK_WLDS_WAVES"); return e ? atoi(e) : 0; }();   // measurement knob: 2 / 4 waves per workgroup (0 = auto)
+        // narrow layers (N < 8192: out_filter_dense / out_proj / l3 of a 7B block) with a workspace from the caller: four waves per workgroup AND a split
+        // over K across workgroups, partial sums through ws (see skinny_nw_kernel SPLITK)
+        static const int sk_env = [] { const char* e = getenv("EVO_SK_SPLITK"); return e ? atoi(e) : 1; }();      // measurement knob: 0 off
+        static const int skm_env = [] { const char* e = getenv("EVO_SK_SPLITK_MINM"); return e ? atoi(e) : 17; }();
+        // (K = 4,096 at <= 32 rows: four chunks per slice are too short a run -- 2.0 against 2.45 TB/s at 17 rows -- the k-split form keeps those)
+        if (ws && sk_env && nw_env && ns_env < 0 && K % 256 == 0 && K >= 1024 && N < 8192 && N >= 1024 && N % 64 == 0 && M >= skm_env && (K >= 8192 || M > 32)) {
+            int64_t slices = (256 + N / 64 - 1) / (N / 64);              // a workgroup per CU
+            if (slices > K / 256) slices = K / 256;
+            if (slices > 8) slices = 8;
+            if (slices >= 2 && ws_bytes >= slices * M * N * 4 && ((uintptr_t)ws & 15) == 0) {
+                const dim3 grid((unsigned)(N / 64), (unsigned)slices);
+#define EVO_SNK(MT) hipLaunchKernelGGL((skinny_nw_kernel<MT, 4, true>), grid, dim3(256), 0, s, (const uint4*)x, (const uint4*)w, (const uint16_t*)nullptr,       \
+                                       (const uint16_t*)nullptr, (uint16_t*)nullptr, (int)M, (int)N, (int)(K / 8), (float*)ws)
+                if (M <= 16) EVO_SNK(1); else if (M <= 32) EVO_SNK(2); else if (M <= 48) EVO_SNK(3); else EVO_SNK(4);
+#undef EVO_SNK
+                hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((M * N / 4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, (const uint16_t*)bias,
+                                   (const uint16_t*)residual, (uint16_t*)y, (int)M, (int)N, (int)slices);
+                return evo_launch_status();
+            }
+        }
         if (K % 256 == 0 && N >= 8192 && nw_env && M >= nwm_env && ns_env < 0) {
             const int wv = nww_env ? nww_env : (N >= 256 * 64 ? 4 : (N >= 256 * 48 ? 3 : (N >= 256 * 32 ? 2 : 4)));   // a workgroup or more per CU where N allows
 #define EVO_SNW(MT, WV) hipLaunchKernelGGL((skinny_nw_kernel<MT, WV>), dim3((unsigned)((N + 16 * WV - 1) / (16 * WV))), dim3(64 * WV), 0, s, (const uint4*)x, \

@@ -35,7 +35,7 @@ _SIGNATURES = {
     "evo_rope_qk_bf16": ([_PTR, _PTR, _PTR, _I64, _I64, _I64, _I64, _F32, _PTR], _c.c_int),
     "evo_attn_fwd_causal_bf16": ([_PTR] * 4 + [_I64] * 14 + [_F32, _PTR, _PTR], _c.c_int),
     "evo_attn_decode_bf16": ([_PTR] * 4 + [_I64] * 11 + [_PTR] * 3 + [_I64, _F32, _PTR], _c.c_int),
-    "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
+    "evo_linear_small_m_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR, _I64, _PTR], _c.c_int),
     "evo_linear_mfma_bf16": ([_PTR] * 5 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_mlp_gate_mfma_bf16": ([_PTR] * 3 + [_I64] * 3 + [_PTR], _c.c_int),
     "evo_hyena_ct": ([_PTR] * 9 + [_I64] * 13 + [_PTR], _c.c_int),
@@ -297,9 +297,11 @@ class HipOps:
         M, K = x.shape
         N = w.shape[0]
         y = res if res is not None else (out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
+        # 17-64 rows on a narrow layer (N < 8192): a workspace for the partial sums of the split over K (csrc/gemv.hip skinny_nw_kernel SPLITK)
+        ws = torch.empty(8 * M * N, dtype=torch.float32, device=x.device) if (M > 16 and N < 8192 and K % 256 == 0 and N % 64 == 0) else None
         with self._t("gemv"):
             _check(self.lib.evo_linear_small_m_bf16(x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(res), y.data_ptr(),
-                                                    M, N, K, _stream()), "evo_linear_small_m_bf16")
+                                                    M, N, K, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "evo_linear_small_m_bf16")
         return y
 
     @staticmethod

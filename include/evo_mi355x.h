@@ -46,7 +46,7 @@ extern "C" {
  *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set);
  *      evo_rope_qk_bf16 and evo_rope_append_decode_bf16 gained `q_scale`, evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 accept
  *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply); evo_linear_small_m_bf16
- *      takes up to 64 rows; evo_hyena_ct gained `y_row_pitch` (rows of y between two batch rows: the scoring path runs the 512 k main tokens
+ *      takes up to 64 rows and an optional workspace (`ws`, `ws_bytes`: split over K across workgroups for the narrow layers); evo_hyena_ct gained `y_row_pitch` (rows of y between two batch rows: the scoring path runs the 512 k main tokens
  *      of every row through the operator and the one token behind them through the single-token launch, see below). */
 #define EVO_ABI_VERSION 10
 int evo_abi_version(void);
@@ -238,9 +238,12 @@ int evo_attn_decode_bf16(const void* q, const void* k, const void* v, void* o,
  * y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]) (+ residual [M, N]);  1 <= M <= 64 (ABI 10; 16 before), K % 8 == 0 (K % 32 == 0
  * for M > 8), all bf16, fp32 accumulate, one rounding.  Weight-streaming (HBM-bound) forms: dot2 on the VALU up to
  * M = 4, v_mfma_f32_16x16x32_bf16 with the batch rows on the MFMA's N side from M = 5 -- one to four tiles of 16 rows per weight pass
- * (17-64 rows: the pooled decode step of 17-64 live streams); `residual` may alias `y`. */
+ * (17-64 rows: the pooled decode step of 17-64 live streams); `residual` may alias `y`.  From 5 rows on layers with N >= 8192 and K % 256 == 0 the
+ * weight is requested in whole 512-byte row pieces and the x rows of a 256-k chunk are shared by the workgroup's waves through LDS (csrc/gemv.hip
+ * skinny_nw_kernel).  `ws` (ABI 10; may be NULL): a 16-byte aligned fp32 workspace of `ws_bytes` >= 8 M N 4 bytes lets the narrow layers (N < 8192) at
+ * 17-64 rows split K over workgroups -- partial sums through ws, added in a fixed order by a second small launch; without it they run the k-split form. */
 int evo_linear_small_m_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y,
-                            int64_t M, int64_t N, int64_t K, void* stream);
+                            int64_t M, int64_t N, int64_t K, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- dense layer on the MFMA pipe (prefill) --------------------------------------------------------------
  * replaces the cuBLAS nn.Linear GEMMs of the attention block: Wqkv (with bias) and out_proj (+ residual)
