@@ -830,10 +830,16 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_n_kernel(const uint4* __res
 // SPLITK (N < 8192, the two N = 4,096 layers of a block): blockIdx.y is a slice of the 256-k chunks; the slice's fp32 partial sums go to
 // ws [slices][M][N] and skinny_reduce_kernel adds them in slice order (+ bias, + residual, one rounding) -- 64 n groups x 4 slices = a workgroup
 // per CU with x still shared four ways, where the k-split form is L2-bound on x (2.1 TB/s at 32 rows).
-template <int MT, int WAVES, bool SPLITK = false>
+// GATE (WAVES = 4): the gated MLP's first half [REF stripedhyena/layers.py ParallelGatedMLP: gelu(l1 x) * l2 x] in one launch -- a workgroup's 64 weight rows are
+// 32 rows of W1 (waves 0, 1) and the MATCHING 32 rows of W2 (waves 2, 3): one block of the grouped layout (`gate_layout` 1: HipOps.pack_gate_weights), or rows
+// c .. c + 31 and I + c .. of the plain [W1; W2] (2).  Waves 2, 3 hand their z2 tiles over through LDS; z1, z2 are rounded to bf16 (the dense layer's outputs),
+// the gate is evaluated in fp32 and rounded once: bit for bit the dense layer + evo_gelu_gate_bf16.  N = 2 I, y = a [M, I].
+template <int MT, int WAVES, bool SPLITK = false, bool GATE = false>
 __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                                const uint16_t* __restrict__ bias, const uint16_t* res,
-                                                               uint16_t* y, int M, int N, int nvec, float* __restrict__ ws = nullptr) {   // res may alias y
+                                                               uint16_t* y, int M, int N, int nvec, float* __restrict__ ws = nullptr,
+                                                               int gate_layout = 0) {   // res may alias y
+    static_assert(!GATE || (WAVES == 4 && !SPLITK), "a gated workgroup is one 32 + 32 row block");
     constexpr int KC = MT <= 2 ? 8 : 4;                          // MFMA steps (32 k) per chunk
     constexpr int ROWB = KC * 64 + 16;                           // LDS bytes per row of a chunk (+ 16 pad: b128 accesses at this pitch touch all banks)
     constexpr int PPR = KC * 4;                                  // 16-byte pieces per row of a chunk
@@ -845,7 +851,8 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kb = lane >> 4;
-    const int n0 = (blockIdx.x * WAVES + wave) * 16;
+    const int n0 = GATE && gate_layout == 2 ? (wave < 2 ? blockIdx.x * 32 + wave * 16 : (N >> 1) + blockIdx.x * 32 + (wave - 2) * 16)
+                                            : (blockIdx.x * WAVES + wave) * 16;
     const int n_chunk_all = nvec / PPR;
     const int c_first = SPLITK ? (int)((int64_t)n_chunk_all * blockIdx.y / gridDim.y) : 0;
     const int n_chunk = SPLITK ? (int)((int64_t)n_chunk_all * (blockIdx.y + 1) / gridDim.y) : n_chunk_all;   // chunks [c_first, n_chunk) are this workgroup's
@@ -910,6 +917,34 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_nw_kernel(const uint4* __re
 #undef SW_X_STORE
 #undef SW_W_LOAD
 #undef SW_W_STORE
+    if constexpr (GATE) {
+        // (the last barrier of the chunk loop is behind every wave's last fragment read: xs is free)
+        float* ex = (float*)&xs[0][0];                           // [2 waves][MT][64 lanes] x 16 B <= 4 KiB
+        if (wave >= 2) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) *(gv_f32x4*)(ex + (((wave - 2) * MT + t) * 64 + lane) * 4) = acc[t];
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const int I_ = N >> 1;
+            const int col0 = blockIdx.x * 32 + wave * 16 + 4 * kb;           // this lane's four gated columns
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const gv_f32x4 z2 = *(const gv_f32x4*)(ex + ((wave * MT + t) * 64 + lane) * 4);
+                const int m = 16 * t + r16;
+                if (m < M && col0 < I_) {
+                    const f32x2_t ua = {round_bf(acc[t][0]), round_bf(acc[t][1])}, ga = {round_bf(z2[0]), round_bf(z2[1])};
+                    const f32x2_t ub = {round_bf(acc[t][2]), round_bf(acc[t][3])}, gb = {round_bf(z2[2]), round_bf(z2[3])};
+                    const f32x2_t oa = gelu_gate2(ua, ga), ob = gelu_gate2(ub, gb);
+                    uint2 o;
+                    o.x = pack_bf2(oa[0], oa[1]);
+                    o.y = pack_bf2(ob[0], ob[1]);
+                    *(uint2*)(y + (int64_t)m * I_ + col0) = o;               // (I % 32 == 0: whole groups of four)
+                }
+            }
+        }
+        return;
+    }
     if constexpr (SPLITK) {
         float* wsl = ws + (int64_t)blockIdx.y * M * N;
 #pragma unroll
@@ -1091,6 +1126,17 @@ static int mlp_gate_launch(const void* x, const void* scale, const void* w12, vo
 
 extern "C" int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K,
                                          int64_t grouped, void* stream) {
+    if (M >= 5 && M <= 64) {
+        // 5-64 rows: the MFMA weight-streaming form with the gate in its epilogue (skinny_nw_kernel GATE), both weight layouts
+        if (I <= 0 || I % 32 != 0 || K <= 0 || K % 256 != 0 || I > 0x1fffffff) return -1;
+        hipStream_t s = (hipStream_t)stream;
+#define EVO_SNG(MT) hipLaunchKernelGGL((skinny_nw_kernel<MT, 4, false, true>), dim3((unsigned)(I / 32)), dim3(256), 0, s, (const uint4*)x, (const uint4*)w12,   \
+                                       (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)a, (int)M, (int)(2 * I), (int)(K / 8), (float*)nullptr,     \
+                                       grouped ? 1 : 2)
+        if (M <= 16) EVO_SNG(1); else if (M <= 32) EVO_SNG(2); else if (M <= 48) EVO_SNG(3); else EVO_SNG(4);
+#undef EVO_SNG
+        return evo_launch_status();
+    }
     return mlp_gate_launch(x, nullptr, w12, a, M, I, K, 0.f, grouped, (hipStream_t)stream);
 }
 

@@ -184,6 +184,8 @@ class HipOps:
         # whole tiles and the one token behind them through the fused single-token launch, from the operator's end state; False: the ragged last
         # tile (one valid step at a full tile's issue time) inside the operator, the tail tokens' projections through the weight-streaming launch
         self.hyena_tail_split = True
+        # round 6: the gated MLP's first half at 5-64 rows as ONE MFMA weight-streaming launch (False: dot2 launch up to 8 rows with a norm, dense layer + gate kernel above)
+        self.gate_small_m_mfma = True
         self.hyena_table_guard = True     # Hyena layers whose filter the bf16 hi / lo operand tables cannot hold run the modal kernels (hyena_tables.table_precision)
         # all_gemm_mfma = False puts the plain dense layers (l3, the unembedding of model(ids)) back on hipBLASLt through torch.addmm:
         # the library is 1-3 % faster on l3's shape (K = 11,008; profiles/r03_gemm_notes.txt) -- bench.py times that leg beside the headline
@@ -961,6 +963,18 @@ class HipOps:
                        "evo_mlp_gate_mfma_bf16")
             if r:
                 a[M - r:] = self.mlp_gate(x[M - r:], w12, w12g=w12g if w12 is None else None)
+            return a
+        ok_mem = (x.is_cuda and x.dtype == torch.bfloat16 and wsrc.dtype == torch.bfloat16 and x.is_contiguous() and wsrc.is_contiguous()
+                  and (norm_scale is None or (norm_scale.dtype == torch.bfloat16 and norm_scale.is_contiguous())))
+        if self.gate_small_m_mfma and 5 <= M <= 64 and K % 256 == 0 and I % 32 == 0 and ok_mem:
+            # round 6: 5-64 rows on the MFMA weight-streaming form with the gate in its epilogue (csrc/gemv.hip skinny_nw_kernel GATE; 512-byte weight
+            # requests, x shared by the workgroup: 5.4 TB/s of weights at 8 rows where the dot2 launch runs 3.6); the norm as its own small pass in front
+            if norm_scale is not None:
+                x = self.rmsnorm(x, None, norm_scale, eps)
+            a = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+            with self._t("gemv_gate"):
+                _check(self.lib.evo_mlp_gate_small_m_bf16(x.data_ptr(), wsrc.data_ptr(), a.data_ptr(), M, I, K, grouped, _stream()),
+                       "evo_mlp_gate_small_m_bf16")
             return a
         if ((1 <= M <= 4 or (M <= 8 and K == 4096 and norm_scale is not None)) and x.is_cuda and x.dtype == torch.bfloat16 and wsrc.dtype == torch.bfloat16 and x.is_contiguous()
                 and wsrc.is_contiguous() and K % 8 == 0 and I % 2 == 0 and (not grouped or I % 32 == 0)

@@ -43,7 +43,8 @@ extern "C" {
  *      evo_mlp_gate_mfma_nf_bf16, evo_linear_t_mfma_nf_bf16 (the same launches with a per-row factor in / the rows' sums of squares
  *      out) and evo_rms_finalize_f32 added; no signature changed.
  *  10: evo_probe_copy_f4 and evo_probe_mfma_bf16 added (the box-calibration probes of bench.py's `box` block); evo_mlp_gate_small_m_bf16 and
- *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set);
+ *      evo_norm_mlp_gate_small_m_bf16 gained `grouped` (the decode launches read l1 | l2 in the gated MFMA launch's row order: one weight set), evo_mlp_gate_small_m_bf16
+ *      takes 5-64 rows on an MFMA form;
  *      evo_rope_qk_bf16 and evo_rope_append_decode_bf16 gained `q_scale`, evo_attn_fwd_causal_bf16 / evo_attn_decode_bf16 accept
  *      softmax_scale <= 0 = "queries pre-scaled" (the prefill attention kernel without its per-score multiply); evo_linear_small_m_bf16
  *      takes up to 64 rows and an optional workspace (`ws`, `ws_bytes`: split over K across workgroups for the narrow layers); evo_hyena_ct gained `y_row_pitch` (rows of y between two batch rows: the scoring path runs the 512 k main tokens
@@ -316,7 +317,10 @@ int evo_norm_linear_small_m_bf16(const void* x, const void* scale, const void* w
  * a [M, I] bf16 = gelu_erf(x . W1^T) * (x . W2^T) with w12 [2I, K] = [W1; W2] bf16, x [M, K] bf16; 1 <= M <= 4,
  * I % 2 == 0, K % 8 == 0.  Both products are rounded to bf16 before the gate, as the unfused layers store them.
  * `grouped` != 0 (ABI 10): w12 is given in the row order of evo_mlp_gate_mfma_bf16's w12g -- blocks of 64 rows = 32 rows of W1 followed
- * by the same 32 rows of W2 (I % 32 == 0) -- so that ONE copy of l1 | l2 serves the prefill launch and the decode launches. */
+ * by the same 32 rows of W2 (I % 32 == 0) -- so that ONE copy of l1 | l2 serves the prefill launch and the decode launches.
+ * 5 <= M <= 64 (ABI 10; I % 32 == 0, K % 256 == 0, either layout): the MFMA weight-streaming form with the gate in its epilogue (csrc/gemv.hip
+ * skinny_nw_kernel GATE) -- the pooled decode step of 5-64 live streams and the BOS sliver rows of a scoring batch; bit for bit
+ * evo_linear_small_m_bf16 on w12 followed by evo_gelu_gate_bf16. */
 int evo_mlp_gate_small_m_bf16(const void* x, const void* w12, void* a, int64_t M, int64_t I, int64_t K, int64_t grouped, void* stream);
 /* same with the post-mixer RMSNorm folded in: x is the residual row, `scale` [K] the norm weight (bit-identical to
  * evo_rmsnorm_bf16 followed by evo_mlp_gate_small_m_bf16); this form also takes 5 <= M <= 8 at K = 4096. */

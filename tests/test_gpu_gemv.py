@@ -211,3 +211,38 @@ def test_hyena_decode_fused_full_width(M):
             assert (ra - rb).abs().max().item() <= tol * rb.abs().max().item()
             assert (fs_a.double() - fs_b.double()).abs().max().item() <= tol * fs_b.double().abs().max().item()
             fs_b.copy_(fs_a); st_b.copy_(st_a)      # (keep the two histories from drifting apart on rounding differences)
+
+
+@pytest.mark.parametrize("M", [5, 8, 13, 16, 17, 32, 40, 64])
+@pytest.mark.parametrize("layout", ["plain", "grouped"])
+@pytest.mark.parametrize("norm", [False, True])
+def test_mlp_gate_mfma_small_m_is_bitwise_dense_layer_then_gate(M, layout, norm):
+    """Round 6: gelu(x W1^T) * (x W2^T) at 5-64 rows as ONE MFMA weight-streaming launch (csrc/gemv.hip skinny_nw_kernel GATE: a workgroup's four waves hold the
+    32 + 32 matching rows of W1 / W2, z2 crosses through LDS) -- bit for bit the dense layer on [W1; W2] followed by the gate kernel,
+    in both weight layouts, with and without the norm in front; and within bf16 rounding of fp64."""
+    from evo_amd.ops import default_ops
+    ops = default_ops()
+    I, K = 11008, 4096
+    g = torch.Generator().manual_seed(M * 91 + 3)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w12 = (torch.randn(2 * I, K, generator=g) * (1.5 / K ** 0.5)).bfloat16().to(DEV)
+    sc = (1.0 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    kw = dict(norm_scale=sc, eps=1e-6) if norm else {}
+    args = (x, w12) if layout == "plain" else (x, None)
+    if layout == "grouped":
+        kw["w12g"] = ops.pack_gate_weights(w12)
+    assert ops.gate_small_m_mfma
+    got = ops.mlp_gate(*args, **kw)
+    xn = ops.rmsnorm(x, None, sc, 1e-6) if norm else x
+    want = ops.gelu_gate(ops.linear(xn, w12, None))             # the composition it replaces: dense layer on [W1; W2] (same MFMA form, same k order), gate kernel
+    assert torch.equal(got, want)
+    if M > 8 or not norm:                                        # (5-8 rows with a norm: the knob falls back to the dot2 launch, another summation order)
+        ops.gate_small_m_mfma = False
+        try:
+            assert torch.equal(ops.mlp_gate(*args, **kw), want)
+        finally:
+            ops.gate_small_m_mfma = True
+    z = xn.double() @ w12.double().t()
+    ref = torch.nn.functional.gelu(z[:, :I].bfloat16().double()) * z[:, I:].bfloat16().double()
+    err = (got.double() - ref).abs()
+    assert (err <= ref.abs() * 2 ** -7 + 2e-3 * ref.abs().max()).all()
