@@ -966,7 +966,8 @@ class HipOps:
             return a
         ok_mem = (x.is_cuda and x.dtype == torch.bfloat16 and wsrc.dtype == torch.bfloat16 and x.is_contiguous() and wsrc.is_contiguous()
                   and (norm_scale is None or (norm_scale.dtype == torch.bfloat16 and norm_scale.is_contiguous())))
-        if self.gate_small_m_mfma and 5 <= M <= 64 and K % 256 == 0 and I % 32 == 0 and ok_mem:
+        # (5-8 rows WITH a norm keep the dot2 launch that norms for itself: one launch -- the BOS sliver of a scoring batch -- against norm pass + 44 us)
+        if self.gate_small_m_mfma and 5 <= M <= 64 and (M > 8 or norm_scale is None) and K % 256 == 0 and I % 32 == 0 and ok_mem:
             # round 6: 5-64 rows on the MFMA weight-streaming form with the gate in its epilogue (csrc/gemv.hip skinny_nw_kernel GATE; 512-byte weight
             # requests, x shared by the workgroup: 5.4 TB/s of weights at 8 rows where the dot2 launch runs 3.6); the norm as its own small pass in front
             if norm_scale is not None:
